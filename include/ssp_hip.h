@@ -1,0 +1,109 @@
+/* ssp_hip.h - C ABI of libssp_hip.so, the MI355X (gfx950) kernels behind the singleshotpose hot path.
+ *
+ * The reference (microsoft/singleshotpose) is pure Python on PyTorch; it has no native interface.  The device
+ * work it performs happens inside ATen/cuDNN ops called from darknet.py / region_loss.py / utils.py.  Each entry
+ * point below names the reference call site (file:line under /root/reference) whose device work it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (never throws); ssp_last_error() gives the thread-local text.
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch); nothing is allocated or freed here, workspaces
+ *     are passed in.  Launches are asynchronous on `stream` (a hipStream_t passed as void*); no hidden sync.
+ *   - activations are fp32 NHWC: pixel p = (b*H + y)*W + x, channel c at base[p*ld + c]; `ld` (floats per pixel)
+ *     may exceed the channel count so a call can read/write a channel slice of a wider buffer (route/concat).
+ *   - packed filters are fp32 [rows][R*R][cols] with cols contiguous (see ssp_repack_*).
+ */
+#ifndef SSP_HIP_H
+#define SSP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ssp_last_error(void);
+int ssp_abi_version(void);
+
+/* ---- convolution (stride 1, "same" padding, R = 1 or 3): nn.Conv2d at darknet.py:156,160 ------------------- */
+
+/* out[p][co] (+)= sum_{tap,ci} in[p + tap][ci] * wt[co][tap][ci]  (+ bias[co]);  wt from ssp_repack_fwd.
+ * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(Cout))][Cout][2] per-tile (mean, M2) of the raw output,
+ * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157). */
+int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream);
+int ssp_conv_stats_tile_m(int Cout);
+
+/* data gradient (autograd of nn.Conv2d, train.py:103): dx[p][ci] (+)= sum dy[p - tap][co] * w[co][ci][tap];
+ * same contraction as ssp_conv_fwd with `wt` from ssp_repack_dgrad; Cout_dy = channels of dy (multiple of 4). */
+int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
+                   int lddx, int R, int accumulate, void* stream);
+
+/* filter gradient: dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]; dw is [Cout][R*R][Cin] packed and must be
+ * zeroed by the caller (split reduction uses fp32 atomics). */
+int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                   int ldx, int R, void* stream);
+
+/* ---- BatchNorm2d(eps) + LeakyReLU(slope) (+ 2x2/2 max-pool): darknet.py:157,162,172 ------------------------- */
+int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                        float* mean, float* invstd, float* scale, float* shift, void* stream);
+int ssp_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
+                        void* stream);
+/* out = [maxpool2x2](leaky(scale*x + shift)); H, W are the un-pooled sizes */
+int ssp_bn_act_fwd(const float* x, int ldx, float* out, int ldo, const float* scale, const float* shift, int C, int B,
+                   int H, int W, int pool, float slope, void* stream);
+/* g = gradient wrt the (pooled) activation; dx (may alias x) = gradient wrt the raw conv output;
+ * partial: workspace of ssp_bn_bwd_blocks()*C*2 floats; c1, c2: C floats each. */
+int ssp_bn_bwd_blocks(void);
+int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
+                   const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W, int pool,
+                   float slope, int training, float* partial, float* dgamma, float* dbeta, float* c1, float* c2,
+                   void* stream);
+/* out[c] = sum_p g[p][c]  (bias gradient of the linear head conv) */
+int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream);
+
+/* ---- layout / index kernels -------------------------------------------------------------------------------- */
+int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream);
+int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream);
+/* conv.weight (Cout,Cin,R,R) (cfg.py:157,175) -> [Cout][R*R][Cinp] */
+int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream);
+/* conv.weight -> [Cin][R*R][Coutp], taps flipped */
+int ssp_repack_dgrad(const float* w, float* out, int Cout, int Cin, int Coutp, int R, void* stream);
+/* packed gradient [Cout][R*R][Cinp] -> (Cout,Cin,R,R) */
+int ssp_unpack_grad(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, void* stream);
+/* Reorg(2) (darknet.py:16-35) on NHWC: dst[b,y/2,x/2,((y&1)*2+(x&1))*C+c] = src[b,y,x,c]; backward = inverse */
+int ssp_reorg(const float* src, int lds, float* dst, int ldd, int C, int B, int H, int W, int backward,
+              int accumulate, void* stream);
+/* route (darknet.py:96-106): dst[p][0..C) (+)= src[p][0..C) */
+int ssp_copy_channels(const float* src, int lds, float* dst, int ldd, int C, int64_t M, int accumulate, void* stream);
+/* nn.MaxPool2d(2,2) (darknet.py:172) standalone */
+int ssp_maxpool_fwd(const float* x, int ldx, float* out, int ldo, int C, int B, int H, int W, void* stream);
+int ssp_maxpool_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, int C, int B, int H, int W,
+                    int accumulate, void* stream);
+
+/* ---- RegionLoss (region_loss.py:9-175, region_loss_multi.py:9-189, utils.py:138-187) ----------------------- */
+/* out, grad: (nB, nA*(2K+1+nC), nH, nW) NCHW contiguous; target: (nB, 50*(2K+3)) float or double on the device;
+ * partials: nB*8 floats; stats[8] = {loss_x, loss_y, loss_conf, loss_cls, total, nGT, nCorrect, nProposals}. */
+int ssp_region_loss(const float* out, const void* target, int target_is_f64, float* grad, float* partials,
+                    float* stats, int nB, int nA, int nC, int nH, int nW, int num_keypoints, float noobject_scale,
+                    float object_scale, float coord_scale, float class_scale, float thresh, int conf_on, int multi,
+                    const float* anchors, int anchor_step, void* stream);
+/* get_region_boxes (utils.py:216-296): boxes[b][2K+4] = {2K coords, det_conf, cls_max_conf, cls_max_id, conf} */
+int ssp_region_decode_argmax(const float* out, float* boxes, int nB, int nA, int nC, int nH, int nW,
+                             int num_keypoints, int only_objectness, void* stream);
+
+/* ---- PnP (utils.py:86-100: cv2.solvePnP ITERATIVE + cv2.Rodrigues) ----------------------------------------- */
+/* batched: pts3d [n][N][3], pts2d [n][N][2], K [n][9] (row-major) doubles on the device -> Rt [n][12] = R (9) | t (3) */
+int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N, int max_iter,
+                    void* stream);
+
+/* ---- timed-launch bookkeeping (bench.py roofline): HIP events around every launch of a kernel family -------- */
+int ssp_prof_enable(int on);
+/* ms[k], work[k] (FLOPs or bytes), count[k] for k in 0..ssp_prof_nkinds()-1; synchronises on the recorded events */
+int ssp_prof_nkinds(void);
+int ssp_prof_collect(double* ms, double* work, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSP_HIP_H */

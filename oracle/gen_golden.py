@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by running the REAL reference code (imported read-only from /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):  python oracle/gen_golden.py
+Nothing from the reference is copied into the repo: its modules are imported (darknet.py, utils.py) or, for
+region_loss.py / region_loss_multi.py, read as text, given the three mechanical patches SURVEY.md section 8(c) lists
+(`.data[0]` -> `.item()`, `np.sum(list)` -> `sum(list)`, torch.cuda.* -> CPU) in memory, and exec'd.
+Inputs are seeded; parameters come from oracle.darknet_ref.seeded_state so tests can rebuild them anywhere.
+"""
+import io
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+
+from oracle.darknet_ref import seeded_state, write_weights  # noqa: E402
+
+
+def import_reference():
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))   # utils.py:10 imports cv2; never called here
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self             # hard-coded .cuda() calls -> CPU
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.LongTensor = torch.LongTensor
+    import utils as ref_utils
+    import cfg as ref_cfg
+    import darknet as ref_darknet
+    return ref_utils, ref_cfg, ref_darknet
+
+
+def load_patched(path, name, extra_path=None):
+    src = open(path).read()
+    src = src.replace('.data[0]', '.item()')
+    src = src.replace('np.sum(loss_xs)', 'sum(loss_xs)').replace('np.sum(loss_ys)', 'sum(loss_ys)')
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    if extra_path:
+        sys.path.insert(0, extra_path)
+    exec(compile(src, path, 'exec'), mod.__dict__)
+    return mod
+
+
+def make_targets(rs, nB, ngt, multi=False, dtype=np.float64):
+    """(nB, 50*21) labels: class, 9 (x,y) in (0.2,0.8), x/y range; rows after `ngt[b]` are zero."""
+    t = np.zeros((nB, 50, 21), dtype=dtype)
+    for b in range(nB):
+        for k in range(ngt[b]):
+            t[b, k, 0] = rs.randint(0, 13) if multi else 0
+            c = rs.uniform(0.2, 0.8, 2)
+            t[b, k, 1:3] = c
+            t[b, k, 3:19] = (c[None, :] + rs.uniform(-0.12, 0.12, (8, 2))).reshape(-1)
+            t[b, k, 19:21] = rs.uniform(0.1, 0.4, 2)
+    return t.reshape(nB, -1)
+
+
+def plant_good_cells(out, tgt, nA, nC, rs):
+    """Make some predictions land near their GT so conf_mask suppression, tconf>0 and recall are exercised."""
+    nB, _, nH, nW = out.shape
+    o = out.reshape(nB, nA, 19 + nC, nH, nW)
+    t = tgt.reshape(nB, 50, 21)
+    for b in range(nB):
+        for k in range(50):
+            if t[b, k, 1] == 0:
+                break
+            gi, gj = int(t[b, k, 1] * nW), int(t[b, k, 2] * nH)
+            for a in range(nA):
+                fx, fy = t[b, k, 1] * nW - gi, t[b, k, 2] * nH - gj
+                o[b, a, 0, gj, gi] = np.log(max(fx, 1e-3) / max(1 - fx, 1e-3)) + rs.normal(0, 0.05)
+                o[b, a, 1, gj, gi] = np.log(max(fy, 1e-3) / max(1 - fy, 1e-3)) + rs.normal(0, 0.05)
+                for i in range(1, 9):
+                    o[b, a, 2 * i, gj, gi] = t[b, k, 1 + 2 * i] * nW - gi + rs.normal(0, 0.05)
+                    o[b, a, 2 * i + 1, gj, gi] = t[b, k, 2 + 2 * i] * nH - gj + rs.normal(0, 0.05)
+    return o.reshape(out.shape)
+
+
+def run_loss(mod_cls, out, tgt, epoch, **attrs):
+    loss_mod = mod_cls(**attrs.pop('ctor', {}))
+    for k, v in attrs.items():
+        setattr(loss_mod, k, v)
+    o = torch.from_numpy(out).clone().requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        loss = loss_mod(o, torch.from_numpy(tgt), epoch)
+    loss.backward()
+    line = buf.getvalue().strip()
+    return float(loss), o.grad.numpy().copy(), line
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref_utils, ref_cfg, ref_darknet = import_reference()
+    rl = load_patched(os.path.join(REF, 'region_loss.py'), 'ref_region_loss')
+
+    # ---- RegionLoss, single object: exactly one label per image (the only case the reference can run) ----
+    rs = np.random.RandomState(1)
+    nB = 4
+    out = (rs.standard_normal((nB, 20, 13, 13)) * 0.5).astype(np.float32)
+    tgt = make_targets(rs, nB, [1] * nB)
+    out = plant_good_cells(out, tgt, 1, 1, rs).astype(np.float32)
+    rec = dict(output=out, target=tgt)
+    for epoch in (20, 0):
+        loss, grad, line = run_loss(rl.RegionLoss, out, tgt, epoch)
+        rec['loss_e%d' % epoch], rec['grad_e%d' % epoch], rec['line_e%d' % epoch] = loss, grad, line
+    # float32 labels (the test-time loader, dataset.py:118) and non-default scales (cfg values, yolo-pose.cfg)
+    loss, grad, line = run_loss(rl.RegionLoss, out, tgt.astype(np.float32), 20, noobject_scale=0.1, coord_scale=2.0)
+    rec['loss_f32'], rec['grad_f32'], rec['line_f32'] = loss, grad, line
+    np.savez_compressed(os.path.join(GOLD, 'region_single.npz'), **rec)
+    print('region_single', rec['line_e20'])
+
+    # ---- RegionLoss, multi object ----
+    mdir = os.path.join(REF, 'multi_obj_pose_estimation')
+    # region_loss_multi does `from utils_multi import *`; utils_multi imports cv2 (stubbed) as well
+    rlm = load_patched(os.path.join(mdir, 'region_loss_multi.py'), 'ref_region_loss_multi', extra_path=mdir)
+    anchors = [1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018, 3.9910, 3.4879, 5.8851]
+    rs = np.random.RandomState(2)
+    nB, nA, nC = 3, 5, 13
+    out = (rs.standard_normal((nB, nA * 32, 13, 13)) * 0.5).astype(np.float32)
+    tgt = make_targets(rs, nB, [3, 1, 8], multi=True)
+    out = plant_good_cells(out, tgt, nA, nC, rs).astype(np.float32)
+    rec = dict(output=out, target=tgt, anchors=np.array(anchors))
+    for epoch in (20, 0):
+        loss, grad, line = run_loss(rlm.RegionLoss, out, tgt, epoch,
+                                    ctor=dict(num_keypoints=9, num_classes=nC, anchors=anchors, num_anchors=nA,
+                                              pretrain_num_epochs=15))
+        rec['loss_e%d' % epoch], rec['grad_e%d' % epoch], rec['line_e%d' % epoch] = loss, grad, line
+    np.savez_compressed(os.path.join(GOLD, 'region_multi.npz'), **rec)
+    print('region_multi', rec['line_e20'])
+
+    # ---- get_region_boxes ----
+    rs = np.random.RandomState(3)
+    rec = {}
+    for name, shape in (('a', (1, 20, 13, 13)), ('b', (2, 20, 21, 21))):
+        o = rs.standard_normal(shape).astype(np.float32)
+        box = ref_utils.get_region_boxes(torch.from_numpy(o), 1, 9)
+        rec['out_' + name] = o
+        rec['box_' + name] = np.array([float(v) for v in box], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, 'decode.npz'), **rec)
+    print('decode', rec['box_a'][-3:])
+
+    # ---- Reorg (bit-exact) ----
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((2, 8, 6, 10)).astype(np.float32)
+    y = ref_darknet.Reorg(2)(torch.from_numpy(x)).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'reorg.npz'), x=x, y=y)
+
+    # ---- Darknet on the tiny cfg: eval forward, train forward, gradients of sum(out * probe) ----
+    def run_net(cfgfile, B, H, W, seed, with_grad, tag, keep_layers=()):
+        blocks = ref_cfg.parse_cfg(cfgfile)
+        state = seeded_state(blocks, seed)
+        wpath = '/tmp/_gold_%s.weights' % tag
+        write_weights(wpath, blocks, state)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ref_darknet.Darknet(cfgfile)
+        model.load_weights(wpath)
+        rs = np.random.RandomState(seed + 100)
+        x = rs.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+        rec = dict(x=x) if x.size < 200000 else dict(x_seed=np.array([seed + 100]))   # big inputs are re-drawn from the seed
+        model.eval()
+        with torch.no_grad():
+            rec['y_eval'] = model(torch.from_numpy(x)).numpy()
+        if with_grad:
+            model.train()
+            y = model(torch.from_numpy(x))
+            probe = rs.standard_normal(y.shape).astype(np.float32)
+            (y * torch.from_numpy(probe)).sum().backward()
+            rec['y_train'] = y.detach().numpy()
+            rec['probe'] = probe
+            for n, p in model.named_parameters():
+                g = p.grad.numpy()
+                rec['gnorm/' + n] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())])
+                if g.size <= 4096:
+                    rec['grad/' + n] = g
+                else:
+                    rec['gslice/' + n] = g.reshape(-1)[:: max(1, g.size // 512)][:512].copy()
+            for n, b in model.named_buffers():
+                if 'running' in n:
+                    rec['buf/' + n] = b.numpy().copy()
+        np.savez_compressed(os.path.join(GOLD, 'darknet_%s.npz' % tag), **rec)
+        print('darknet', tag, rec['y_eval'].shape, float(np.abs(rec['y_eval']).max()))
+
+    run_net(os.path.join(GOLD, 'tiny-pose.cfg'), 2, 96, 96, 5, True, 'tiny')
+    run_net(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 1, 416, 416, 6, False, 'full_eval')
+    run_net(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 2, 416, 416, 7, True, 'full_train')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of libssp_hip.so (C ABI: include/ssp_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a kernel entry point reports an
+error, this module raises.  Nothing here imports anything under oracle/.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssp_hip.so")
+
+
+class SspError(RuntimeError):
+    pass
+
+
+_lib = None
+
+P = c_void_p
+I = c_int
+F = c_float
+L = c_int64
+
+# name -> argtypes (all return int unless noted)
+_SIGS = {
+    "ssp_abi_version": [],
+    "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "ssp_conv_stats_tile_m": [I],
+    "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
+    "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],
+    "ssp_bn_eval_prepare": [I, P, P, P, P, F, P, P, P, P, P],
+    "ssp_bn_act_fwd": [P, I, P, I, P, P, I, I, I, I, I, F, P],
+    "ssp_bn_bwd_blocks": [],
+    "ssp_bn_act_bwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P, P, P, P, P, P],
+    "ssp_colsum": [P, I, L, I, P, P],
+    "ssp_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
+    "ssp_nhwc_to_nchw": [P, P, I, I, I, I, I, P],
+    "ssp_repack_fwd": [P, P, I, I, I, I, P],
+    "ssp_repack_dgrad": [P, P, I, I, I, I, P],
+    "ssp_unpack_grad": [P, P, I, I, I, I, P],
+    "ssp_reorg": [P, I, P, I, I, I, I, I, I, I, P],
+    "ssp_copy_channels": [P, I, P, I, I, L, I, P],
+    "ssp_maxpool_fwd": [P, I, P, I, I, I, I, I, P],
+    "ssp_maxpool_bwd": [P, I, P, I, P, I, I, I, I, I, I, P],
+    "ssp_region_loss": [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, F, I, I, P, I, P],
+    "ssp_region_decode_argmax": [P, P, I, I, I, I, I, I, I, P],
+    "ssp_pnp_batched": [P, P, P, P, I, I, I, P],
+    "ssp_prof_enable": [I],
+    "ssp_prof_nkinds": [],
+    "ssp_prof_collect": [P, P, P],
+}
+
+PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region")
+
+
+def exported_symbols():
+    """Every entry point include/ssp_hip.h declares (used by the CPU-side ABI test)."""
+    return ["ssp_last_error"] + list(_SIGS.keys())
+
+
+def load():
+    """Load the library (once).  Raises SspError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SspError(
+            "libssp_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C singleshotpose_amd/csrc`; there is no CPU fallback for the HIP path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ssp_last_error.restype = c_char_p
+    lib.ssp_last_error.argtypes = []
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; raise SspError with the library's message on a non-zero return."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.ssp_last_error()
+        raise SspError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
+    return rc
+
+
+def query(name, *args):
+    """Entry points that return a value instead of a status (ssp_abi_version, ssp_conv_stats_tile_m, ...)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,221 @@
+// extern "C" surface of libssp_hip.so (include/ssp_hip.h): argument marshalling, thread-local error text and the
+// HIP-event launch timer used by bench.py.  No kernels here.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ssp_hip.h"
+#include "ssp_common.h"
+
+// ---- kernels' host launchers (defined next to the kernels) ----
+int ssp_conv_tile_m(int Cout);
+int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
+                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int prof_kind,
+                          hipStream_t stream);
+int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                          int ldx, int R, hipStream_t stream);
+int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
+                               const float* beta, float* rmean, float* rvar, float momentum, float eps, float* mean,
+                               float* invstd, float* scale, float* shift, hipStream_t stream);
+int ssp_bn_eval_prepare_launch(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                               float eps, float* mean, float* invstd, float* scale, float* shift, hipStream_t stream);
+int ssp_bn_act_fwd_launch(const float* x, int ldx, float* out, int ldo, const float* scale, const float* shift, int C,
+                          int B, int H, int W, int pool, float slope, hipStream_t stream);
+int ssp_bn_bwd_blocks_impl(void);
+int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
+                          int pool, float slope, int training, float* partial, float* dgamma, float* dbeta, float* c1,
+                          float* c2, hipStream_t stream);
+int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
+int ssp_nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int H, int W, int Cp, int ld, hipStream_t stream);
+int ssp_nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int H, int W, int ld, hipStream_t stream);
+int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
+int ssp_unpack_grad_launch(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
+int ssp_repack_dgrad_launch(const float* w, float* out, int Cout, int Cin, int Coutp, int R, hipStream_t stream);
+int ssp_reorg_launch(const float* src, int lds_, float* dst, int ldd, int C, int B, int H, int W, int backward,
+                     int accumulate, hipStream_t stream);
+int ssp_copy_channels_launch(const float* src, int lds_, float* dst, int ldd, int C, int64_t M, int accumulate,
+                             hipStream_t stream);
+int ssp_maxpool_fwd_launch(const float* x, int ldx, float* out, int ldo, int C, int B, int H, int W, hipStream_t stream);
+int ssp_maxpool_bwd_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, int C, int B, int H,
+                           int W, int accumulate, hipStream_t stream);
+int ssp_region_loss_launch(const float* out, const void* target, int target_is_f64, float* grad, float* partials,
+                           float* stats, int nB, int nA, int nC, int nH, int nW, int num_keypoints,
+                           float noobject_scale, float object_scale, float coord_scale, float class_scale, float thresh,
+                           int conf_on, int multi, const float* anchors, int anchor_step, hipStream_t stream);
+int ssp_region_decode_argmax_launch(const float* out, float* boxes, int nB, int nA, int nC, int nH, int nW,
+                                    int num_keypoints, int only_objectness, hipStream_t stream);
+int ssp_pnp_batched_launch(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N,
+                           int max_iter, hipStream_t stream);
+
+// ---- error text ----
+static thread_local char g_err[512] = "";
+void ssp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- launch timer ----
+namespace {
+struct ProfRec {
+  int kind;
+  hipEvent_t start, stop;
+  double work;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
+}  // namespace
+
+SspProfScope::SspProfScope(int kind, hipStream_t s, double work) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.kind = kind;
+  r.work = work;
+  if (!g_free_events.empty()) {
+    r.start = g_free_events.back().first;
+    r.stop = g_free_events.back().second;
+    g_free_events.pop_back();
+  } else {
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  }
+  (void)hipEventRecord(r.start, s);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+SspProfScope::~SspProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_recs[slot].stop, stream);
+}
+
+extern "C" {
+
+const char* ssp_last_error(void) { return g_err; }
+int ssp_abi_version(void) { return 1; }
+
+int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream) {
+  return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate,
+                               SSP_PROF_CONV_FWD, (hipStream_t)stream);
+}
+int ssp_conv_stats_tile_m(int Cout) { return ssp_conv_tile_m(Cout); }
+
+int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
+                   int lddx, int R, int accumulate, void* stream) {
+  return ssp_conv_igemm_launch(dy, wt, dx, nullptr, nullptr, B, H, W, Cout_dy, Cin_dx, lddy, lddx, R, accumulate,
+                               SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
+}
+
+int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                   int ldx, int R, void* stream) {
+  return ssp_conv_wgrad_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, R, (hipStream_t)stream);
+}
+
+int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                        float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  return ssp_bn_fwd_finalize_launch(stats, ntile, tile_m, M, C, gamma, beta, running_mean, running_var, momentum, eps,
+                                    mean, invstd, scale, shift, (hipStream_t)stream);
+}
+int ssp_bn_eval_prepare(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
+                        void* stream) {
+  return ssp_bn_eval_prepare_launch(C, gamma, beta, running_mean, running_var, eps, mean, invstd, scale, shift,
+                                    (hipStream_t)stream);
+}
+int ssp_bn_act_fwd(const float* x, int ldx, float* out, int ldo, const float* scale, const float* shift, int C, int B,
+                   int H, int W, int pool, float slope, void* stream) {
+  return ssp_bn_act_fwd_launch(x, ldx, out, ldo, scale, shift, C, B, H, W, pool, slope, (hipStream_t)stream);
+}
+int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
+                   const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W, int pool,
+                   float slope, int training, float* partial, float* dgamma, float* dbeta, float* c1, float* c2,
+                   void* stream) {
+  return ssp_bn_act_bwd_launch(x, ldx, g, ldg, dx, lddx, scale, shift, mean, invstd, C, B, H, W, pool, slope, training,
+                               partial, dgamma, dbeta, c1, c2, (hipStream_t)stream);
+}
+int ssp_bn_bwd_blocks(void) { return ssp_bn_bwd_blocks_impl(); }
+int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream) {
+  return ssp_colsum_launch(g, ldg, M, C, out, (hipStream_t)stream);
+}
+
+int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream) {
+  return ssp_nchw_to_nhwc_launch(src, dst, B, C, H, W, Cpad, ld, (hipStream_t)stream);
+}
+int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream) {
+  return ssp_nhwc_to_nchw_launch(src, dst, B, C, H, W, ld, (hipStream_t)stream);
+}
+int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream) {
+  return ssp_repack_fwd_launch(w, out, Cout, Cin, Cinp, R, (hipStream_t)stream);
+}
+int ssp_repack_dgrad(const float* w, float* out, int Cout, int Cin, int Coutp, int R, void* stream) {
+  return ssp_repack_dgrad_launch(w, out, Cout, Cin, Coutp, R, (hipStream_t)stream);
+}
+int ssp_unpack_grad(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, void* stream) {
+  return ssp_unpack_grad_launch(dwp, grad, Cout, Cin, Cinp, R, (hipStream_t)stream);
+}
+int ssp_reorg(const float* src, int lds, float* dst, int ldd, int C, int B, int H, int W, int backward, int accumulate,
+              void* stream) {
+  return ssp_reorg_launch(src, lds, dst, ldd, C, B, H, W, backward, accumulate, (hipStream_t)stream);
+}
+int ssp_copy_channels(const float* src, int lds, float* dst, int ldd, int C, int64_t M, int accumulate, void* stream) {
+  return ssp_copy_channels_launch(src, lds, dst, ldd, C, M, accumulate, (hipStream_t)stream);
+}
+int ssp_maxpool_fwd(const float* x, int ldx, float* out, int ldo, int C, int B, int H, int W, void* stream) {
+  return ssp_maxpool_fwd_launch(x, ldx, out, ldo, C, B, H, W, (hipStream_t)stream);
+}
+int ssp_maxpool_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, int C, int B, int H, int W,
+                    int accumulate, void* stream) {
+  return ssp_maxpool_bwd_launch(x, ldx, g, ldg, dx, lddx, C, B, H, W, accumulate, (hipStream_t)stream);
+}
+
+int ssp_region_loss(const float* out, const void* target, int target_is_f64, float* grad, float* partials,
+                    float* stats, int nB, int nA, int nC, int nH, int nW, int num_keypoints, float noobject_scale,
+                    float object_scale, float coord_scale, float class_scale, float thresh, int conf_on, int multi,
+                    const float* anchors, int anchor_step, void* stream) {
+  return ssp_region_loss_launch(out, target, target_is_f64, grad, partials, stats, nB, nA, nC, nH, nW, num_keypoints,
+                                noobject_scale, object_scale, coord_scale, class_scale, thresh, conf_on, multi, anchors,
+                                anchor_step, (hipStream_t)stream);
+}
+int ssp_region_decode_argmax(const float* out, float* boxes, int nB, int nA, int nC, int nH, int nW,
+                             int num_keypoints, int only_objectness, void* stream) {
+  return ssp_region_decode_argmax_launch(out, boxes, nB, nA, nC, nH, nW, num_keypoints, only_objectness,
+                                         (hipStream_t)stream);
+}
+
+int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N, int max_iter,
+                    void* stream) {
+  return ssp_pnp_batched_launch(pts3d, pts2d, K, Rt, n, N, max_iter, (hipStream_t)stream);
+}
+
+int ssp_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return SSP_OK;
+}
+int ssp_prof_nkinds(void) { return SSP_PROF_NKINDS; }
+int ssp_prof_collect(double* ms, double* work, int64_t* count) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int k = 0; k < SSP_PROF_NKINDS; ++k) { ms[k] = 0.0; work[k] = 0.0; count[k] = 0; }
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) {
+      ssp_set_error("prof_collect: event query failed");
+      g_recs.clear();
+      return SSP_ERR_HIP;
+    }
+    ms[r.kind] += (double)t;
+    work[r.kind] += r.work;
+    count[r.kind] += 1;
+    g_free_events.emplace_back(r.start, r.stop);
+  }
+  g_recs.clear();
+  return SSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Shared device/host helpers for the singleshotpose hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define SSP_OK 0
+#define SSP_ERR_ARG -1
+#define SSP_ERR_HIP -2
+#define SSP_ERR_UNSUPPORTED -3
+
+// thread-local last-error string (include/ssp_hip.h: ssp_last_error)
+void ssp_set_error(const char* fmt, ...);
+
+#define SSP_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      ssp_set_error(__VA_ARGS__);           \
+      return SSP_ERR_ARG;                   \
+    }                                       \
+  } while (0)
+
+#define SSP_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) {                                                          \
+      ssp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));           \
+      return SSP_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+// Timed-launch bookkeeping (ssp_prof_*): kernel families we report rooflines for.
+enum SspProfKind {
+  SSP_PROF_CONV_FWD = 0,   // implicit-GEMM conv forward launches
+  SSP_PROF_CONV_DGRAD = 1, // same kernel, flipped/transposed filters
+  SSP_PROF_CONV_WGRAD = 2,
+  SSP_PROF_BN_ACT = 3,     // BN finalize/apply/leaky/pool fwd+bwd elementwise family
+  SSP_PROF_LAYOUT = 4,     // repack / transpose / reorg / maxpool
+  SSP_PROF_REGION = 5,     // region loss / decode / pnp
+  SSP_PROF_NKINDS = 6
+};
+
+struct SspProfScope {
+  SspProfScope(int kind, hipStream_t s, double work);
+  ~SspProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Observed dispatch places workgroup b on XCD b%8 (MI355X_MICROARCH.md, "Workgroup dispatch").
+// Remap so that each XCD walks a contiguous chunk of the logical tile order (L2 locality only,
+// never correctness).  Bijective for any nwg (cdna_hip_programming.md §5 "XCD swizzle must be bijective").
+__device__ __forceinline__ int ssp_xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int xcd = bid % nx, idx = bid / nx;
+  int q = nwg / nx, r = nwg % nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

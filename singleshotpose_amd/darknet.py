@@ -1,0 +1,260 @@
+"""Darknet(nn.Module) on hand-written HIP kernels - host-side mirror of the reference's darknet.py.
+
+Same surface as /root/reference/darknet.py:59-394: Darknet(cfgfile), forward(x NCHW fp32) -> raw head
+(B, nA*(2K+1+nC), H/32, W/32), print_network, load_weights, load_weights_until_last, save_weights, attributes
+width/height/test_width/test_height/num_keypoints/anchors/num_anchors/anchor_step/num_classes/seen/iter/header/
+blocks/models/loss.  `models` keeps the reference's module tree (models[i][0] = conv, models[i][1] = bn,
+parameter names models.N.conv{k}.weight / models.N.bn{k}.*) so checkpoints, optimisers and
+`named_parameters()` filters see the same thing; the nn.Conv2d / nn.BatchNorm2d objects are parameter holders only -
+forward never calls them.  All device work goes through libssp_hip.so (engine.Plan); there is no CPU or eager
+fallback: a CPU tensor or a missing library raises.
+"""
+import collections
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .cfg import (load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, resolve_layers, save_conv, save_conv_bn,
+                  save_fc)
+from .engine import Plan, _DarknetFn
+from .region_loss import RegionLoss
+
+
+class _HipOnly(nn.Module):
+    """Structural placeholder: the op runs inside the fused HIP plan, never as a standalone torch module."""
+
+    def forward(self, x):
+        raise RuntimeError("%s is executed by the HIP plan of Darknet.forward; it has no standalone eager path"
+                           % type(self).__name__)
+
+
+class MaxPoolStride1(_HipOnly):
+    pass
+
+
+class Reorg(_HipOnly):
+    def __init__(self, stride=2):
+        super(Reorg, self).__init__()
+        self.stride = stride
+
+
+class GlobalAvgPool2d(_HipOnly):
+    pass
+
+
+class EmptyModule(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class Darknet(nn.Module):
+    def __init__(self, cfgfile):
+        super(Darknet, self).__init__()
+        self.blocks = parse_cfg(cfgfile)
+        self.models = self.create_network(self.blocks)
+        self.loss = self.models[len(self.models) - 1]
+
+        net = self.blocks[0]
+        self.width = int(net['width'])
+        self.height = int(net['height'])
+        if 'test_width' in net:   # the multi-object cfg has no test size / num_keypoints (darknet_multi.py:66-70)
+            self.test_width = int(net['test_width'])
+            self.test_height = int(net['test_height'])
+        if 'num_keypoints' in net:
+            self.num_keypoints = int(net['num_keypoints'])
+
+        if self.blocks[-1]['type'] == 'region':
+            self.anchors = self.loss.anchors
+            self.num_anchors = self.loss.num_anchors
+            self.anchor_step = self.loss.anchor_step
+            self.num_classes = self.loss.num_classes
+
+        self.header = torch.IntTensor([0, 0, 0, 0])
+        self.seen = 0
+        self.iter = 0
+        self._plans = collections.OrderedDict()
+        self._max_plans = 3
+
+    # ---- network construction: same module tree as darknet.py:135-249 ----
+    def create_network(self, blocks):
+        models = nn.ModuleList()
+        prev_filters = 3
+        out_filters = []
+        conv_id = 0
+        for block in blocks:
+            t = block['type']
+            if t == 'net':
+                prev_filters = int(block['channels'])
+                continue
+            elif t == 'convolutional':
+                conv_id += 1
+                bn = int(block['batch_normalize'])
+                filters, k, stride = int(block['filters']), int(block['size']), int(block['stride'])
+                pad = (k - 1) // 2 if int(block['pad']) else 0
+                model = nn.Sequential()
+                if bn:
+                    model.add_module('conv{0}'.format(conv_id), nn.Conv2d(prev_filters, filters, k, stride, pad, bias=False))
+                    model.add_module('bn{0}'.format(conv_id), nn.BatchNorm2d(filters, eps=1e-4))
+                else:
+                    model.add_module('conv{0}'.format(conv_id), nn.Conv2d(prev_filters, filters, k, stride, pad))
+                if block['activation'] == 'leaky':
+                    model.add_module('leaky{0}'.format(conv_id), nn.LeakyReLU(0.1, inplace=True))
+                elif block['activation'] == 'relu':
+                    model.add_module('relu{0}'.format(conv_id), nn.ReLU(inplace=True))
+                prev_filters = filters
+                out_filters.append(prev_filters)
+                models.append(model)
+            elif t == 'maxpool':
+                stride = int(block['stride'])
+                models.append(nn.MaxPool2d(int(block['size']), stride) if stride > 1 else MaxPoolStride1())
+                out_filters.append(prev_filters)
+            elif t == 'avgpool':
+                models.append(GlobalAvgPool2d())
+                out_filters.append(prev_filters)
+            elif t == 'softmax':
+                models.append(nn.Softmax(dim=1))
+                out_filters.append(prev_filters)
+            elif t == 'cost':
+                models.append(EmptyModule())
+                out_filters.append(1)
+            elif t == 'reorg':
+                stride = int(block['stride'])
+                prev_filters = stride * stride * prev_filters
+                out_filters.append(prev_filters)
+                models.append(Reorg(stride))
+            elif t == 'route':
+                ind = len(models)
+                layers = resolve_layers(block['layers'], ind)
+                if len(layers) == 1:
+                    prev_filters = out_filters[layers[0]]
+                elif len(layers) == 2:
+                    assert layers[0] == ind - 1
+                    prev_filters = out_filters[layers[0]] + out_filters[layers[1]]
+                out_filters.append(prev_filters)
+                models.append(EmptyModule())
+            elif t == 'shortcut':
+                ind = len(models)
+                prev_filters = out_filters[ind - 1]
+                out_filters.append(prev_filters)
+                models.append(EmptyModule())
+            elif t == 'connected':
+                filters = int(block['output'])
+                models.append(nn.Linear(prev_filters, filters))
+                prev_filters = filters
+                out_filters.append(prev_filters)
+            elif t == 'region':
+                loss = RegionLoss()
+                anchors = block['anchors'].split(',')
+                loss.anchors = [] if anchors == [''] else [float(i) for i in anchors]
+                loss.num_classes = int(block['classes'])
+                loss.num_anchors = int(block['num'])
+                loss.anchor_step = len(loss.anchors) // loss.num_anchors
+                loss.object_scale = float(block['object_scale'])
+                loss.noobject_scale = float(block['noobject_scale'])
+                loss.class_scale = float(block['class_scale'])
+                loss.coord_scale = float(block['coord_scale'])
+                out_filters.append(prev_filters)
+                models.append(loss)
+            else:
+                print('unknown type %s' % t)
+        return models
+
+    # ---- forward: one autograd node, HIP launches only ----
+    def _plan(self, x):
+        key = (x.size(0), x.size(2), x.size(3), x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            while len(self._plans) >= self._max_plans:
+                self._plans.popitem(last=False)
+            plan = Plan(self, x.size(0), x.size(2), x.size(3), x.device)
+            self._plans[key] = plan
+        else:
+            self._plans.move_to_end(key)
+        return plan
+
+    def _params(self):
+        ps = []
+        for m in self.models:
+            if isinstance(m, nn.Sequential):
+                for p in m.parameters():
+                    ps.append(p)
+        return ps
+
+    def forward(self, x):
+        self.loss = None   # as darknet.py:84
+        if not x.is_cuda:
+            raise RuntimeError("singleshotpose_amd.Darknet runs on the MI355X HIP kernels only: got a %s tensor "
+                               "(no CPU fallback exists; the reference's PyTorch-CPU path lives under oracle/ as a "
+                               "test checker)" % x.device)
+        _lib.load()
+        if x.dim() != 4 or x.size(1) != int(self.blocks[0].get('channels', 3)):
+            raise ValueError("expected a (B,%s,H,W) input" % self.blocks[0].get('channels', 3))
+        x = x.detach().to(torch.float32).contiguous()
+        params = self._params()
+        for p in params:
+            if p.device != x.device:
+                raise RuntimeError("model parameters are on %s but the input is on %s - call model.cuda()" % (p.device, x.device))
+        plan = self._plan(x)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad:
+            return _DarknetFn.apply(plan, self.training, x, *params)
+        return plan.forward(x, self.training)
+
+    def print_network(self):
+        print_cfg(self.blocks)
+
+    # ---- .weights I/O (darknet.py:251-394) ----
+    def _read_weights(self, weightfile):
+        with open(weightfile, 'rb') as fp:
+            header = np.fromfile(fp, count=4, dtype=np.int32)
+            buf = np.fromfile(fp, dtype=np.float32)
+        self.header = torch.from_numpy(header)
+        self.seen = self.header[3]
+        return buf
+
+    def _load_blocks(self, buf, nblocks):
+        start = 0
+        ind = -2
+        for block in self.blocks[:nblocks]:
+            if start >= buf.size:
+                break
+            ind += 1
+            t = block['type']
+            if t == 'convolutional':
+                model = self.models[ind]
+                if int(block['batch_normalize']):
+                    start = load_conv_bn(buf, start, model[0], model[1])
+                else:
+                    start = load_conv(buf, start, model[0])
+            elif t == 'connected':
+                start = load_fc(buf, start, self.models[ind])
+        for plan in self._plans.values():
+            plan.wversion.clear()   # .data.copy_ does not bump the autograd version counter
+
+    def load_weights(self, weightfile):
+        self._load_blocks(self._read_weights(weightfile), len(self.blocks))
+
+    def load_weights_until_last(self, weightfile):
+        # skips the last conv + region (darknet.py:310: range(blocklen-2))
+        self._load_blocks(self._read_weights(weightfile), len(self.blocks) - 2)
+
+    def save_weights(self, outfile, cutoff=0):
+        if cutoff <= 0:
+            cutoff = len(self.blocks) - 1
+        with open(outfile, 'wb') as fp:
+            self.header[3] = int(self.seen)
+            self.header.numpy().tofile(fp)
+            ind = -1
+            for block_id in range(1, cutoff + 1):
+                ind += 1
+                block = self.blocks[block_id]
+                if block['type'] == 'convolutional':
+                    model = self.models[ind]
+                    if int(block['batch_normalize']):
+                        save_conv_bn(fp, model[0], model[1])
+                    else:
+                        save_conv(fp, model[0])
+                elif block['type'] == 'connected':
+                    save_fc(fp, self.models[ind])

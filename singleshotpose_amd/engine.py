@@ -1,0 +1,397 @@
+"""Execution plan for a Darknet cfg on the HIP kernels (libssp_hip.so).
+
+Walks the block list the way Darknet.forward does (/root/reference/darknet.py:82-130) but emits kernel launches
+through the C ABI instead of torch.nn modules.  Activations live in NHWC fp32 buffers owned by torch (allocated once
+per input shape and reused every step); every launch goes to torch's current HIP stream.
+
+Forward per conv block (darknet.py:145-167):
+    repack filters -> ssp_conv_fwd (MFMA implicit GEMM, BN partial statistics in the epilogue)
+    -> ssp_bn_fwd_finalize (train) | ssp_bn_eval_prepare (eval) -> ssp_bn_act_fwd (BN + leaky [+ fused 2x2 max-pool])
+A max-pool block is fused into the preceding conv block when nothing else consumes the un-pooled map.
+route = alias or ssp_copy_channels into a concat buffer; reorg = ssp_reorg.
+
+Backward mirrors it in reverse: ssp_bn_act_bwd (in place over the raw conv output) -> ssp_conv_wgrad ->
+ssp_unpack_grad, and ssp_conv_dgrad into the producer's gradient buffer (accumulating when a map has two consumers).
+"""
+import torch
+
+from . import _lib
+from .cfg import layer_shapes, resolve_layers
+
+BN_EPS = 1e-4        # darknet.py:157
+BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
+
+
+def _ptr(t, offset=0):
+    return t.data_ptr() + 4 * offset
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class _Act(object):
+    """A [pixels][ld] fp32 view: tensor + channel offset."""
+    __slots__ = ('t', 'off', 'C', 'H', 'W', 'ld')
+
+    def __init__(self, t, off, C, H, W, ld):
+        self.t, self.off, self.C, self.H, self.W, self.ld = t, off, C, H, W, ld
+
+    @property
+    def ptr(self):
+        return _ptr(self.t, self.off)
+
+
+class _ConvSpec(object):
+    pass
+
+
+class Plan(object):
+    """Buffers + launch sequence for one (batch, height, width) input shape."""
+
+    def __init__(self, net, B, H, W, device):
+        self.net = net
+        self.B, self.H, self.W = B, H, W
+        self.device = device
+        blocks = net.blocks
+        self.shapes = layer_shapes(blocks, W, H)  # (w, h, c) per layer
+        nl = len(blocks) - 1
+        self.nl = nl
+
+        # ---- consumer analysis (who reads layer l's output) ----
+        consumers = [[] for _ in range(nl)]
+        for ind, block in enumerate(blocks[1:]):
+            t = block['type']
+            if t in ('convolutional', 'maxpool', 'reorg'):
+                if ind > 0:
+                    consumers[ind - 1].append(ind)
+            elif t == 'route':
+                for l in resolve_layers(block['layers'], ind):
+                    consumers[l].append(ind)
+            elif t in ('region', 'cost'):
+                pass
+            else:
+                raise NotImplementedError(
+                    "block type '%s' is outside the yolo-pose hot path (SURVEY.md section 8); not built" % t)
+        self.consumers = consumers
+        # the network output is the last non-region layer
+        self.last = max(i for i, b in enumerate(blocks[1:]) if b['type'] not in ('region', 'cost'))
+
+        f32 = dict(dtype=torch.float32, device=device)
+        in_c = int(blocks[0].get('channels', 3))
+        self.in_c = in_c
+        self.in_cp = _pad4(in_c)
+        self.x_nhwc = torch.empty(B * H * W * self.in_cp, **f32)
+        self.input_act = _Act(self.x_nhwc, 0, self.in_cp, H, W, self.in_cp)
+
+        self.convs = {}      # layer index -> _ConvSpec
+        self.fused_pool = set()   # maxpool layers folded into the preceding conv block
+        self.acts = [None] * nl   # forward outputs
+        self.ops_fwd = []
+        wsz = dsz = 0
+        prev = self.input_act
+        for ind, block in enumerate(blocks[1:]):
+            t = block['type']
+            w, h, c = self.shapes[ind]
+            if t == 'convolutional':
+                k, s = int(block['size']), int(block['stride'])
+                if s != 1 or k not in (1, 3) or (k == 3 and not int(block['pad'])):
+                    raise NotImplementedError("conv size=%d stride=%d pad=%s is outside the yolo-pose hot path" % (k, s, block['pad']))
+                cs = _ConvSpec()
+                cs.ind, cs.k = ind, k
+                cs.bn = int(block['batch_normalize']) != 0
+                act = block['activation']
+                if act not in ('leaky', 'linear', 'relu'):
+                    raise NotImplementedError("activation '%s'" % act)
+                cs.slope = {'leaky': 0.1, 'linear': 1.0, 'relu': 0.0}[act]
+                cs.inp = prev
+                cs.first = prev is self.input_act
+                cs.cin = in_c if cs.first else prev.C
+                cs.cinp = _pad4(cs.cin)
+                cs.cout = c
+                if prev.ld < cs.cinp:
+                    raise NotImplementedError("conv input with a channel count that is not a multiple of 4")
+                cs.H, cs.W = prev.H, prev.W
+                cs.coutp = _pad4(c)
+                seq = net.models[ind]
+                cs.conv = seq[0]
+                cs.bnm = seq[1] if cs.bn else None
+                # fuse a following 2x2/2 max-pool when it is the only consumer
+                nxt = blocks[ind + 2] if ind + 2 < len(blocks) else None
+                cs.pool = bool(cs.bn and nxt is not None and nxt['type'] == 'maxpool' and int(nxt['size']) == 2 and
+                               int(nxt['stride']) == 2 and consumers[ind] == [ind + 1] and cs.H % 2 == 0 and cs.W % 2 == 0)
+                M = B * cs.H * cs.W
+                cs.M = M
+                alloc = torch.empty if cs.coutp == c else torch.zeros
+                cs.raw = alloc(M * cs.coutp, **f32)            # raw conv output (kept for backward)
+                cs.ldraw = cs.coutp
+                cs.needs_act = cs.bn or cs.slope != 1.0
+                if cs.needs_act:
+                    Ho, Wo = (cs.H // 2, cs.W // 2) if cs.pool else (cs.H, cs.W)
+                    cs.out = _Act(alloc(B * Ho * Wo * cs.coutp, **f32), 0, c, Ho, Wo, cs.coutp)
+                else:
+                    cs.out = _Act(cs.raw, 0, c, cs.H, cs.W, cs.coutp)
+                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', c)
+                cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
+                if cs.bn:
+                    cs.stats = torch.empty(cs.ntile * c * 2, **f32)
+                # per-channel vectors: mean, invstd, scale, shift, c1, c2, dgamma, dbeta
+                cs.vec = torch.zeros(8, cs.coutp, **f32)
+                if not cs.bn:
+                    cs.vec[1].fill_(1.0)
+                    cs.vec[2].fill_(1.0)
+                cs.woff, cs.doff = wsz, dsz
+                wsz += c * k * k * cs.cinp
+                dsz += cs.cinp * k * k * cs.coutp if not cs.first else 0
+                self.convs[ind] = cs
+                if cs.pool:
+                    self.fused_pool.add(ind + 1)
+                    self.acts[ind] = None
+                    self.acts[ind + 1] = cs.out
+                else:
+                    self.acts[ind] = cs.out
+                self.ops_fwd.append(('conv', cs))
+                prev = cs.out
+            elif t == 'maxpool':
+                if ind in self.fused_pool:
+                    prev = self.acts[ind]
+                    continue
+                k, s = int(block['size']), int(block['stride'])
+                if k != 2 or s != 2:
+                    raise NotImplementedError("maxpool size=%d stride=%d (MaxPoolStride1, darknet.py:8-14) is not instantiated by the pose cfgs; not built" % (k, s))
+                src = prev
+                out = _Act(torch.empty(B * h * w * src.ld, **f32), 0, c, h, w, src.ld)
+                self.acts[ind] = out
+                self.ops_fwd.append(('maxpool', ind, src, out))
+                prev = out
+            elif t == 'reorg':
+                if int(block['stride']) != 2:
+                    raise NotImplementedError("reorg stride != 2")
+                src = prev
+                out = _Act(torch.empty(B * h * w * c, **f32), 0, c, h, w, c)
+                self.acts[ind] = out
+                self.ops_fwd.append(('reorg', ind, src, out))
+                prev = out
+            elif t == 'route':
+                layers = resolve_layers(block['layers'], ind)
+                srcs = [self.acts[l] for l in layers]
+                if any(s is None for s in srcs):
+                    raise RuntimeError("route to a layer whose output was fused away")
+                if len(layers) == 1:
+                    self.acts[ind] = srcs[0]
+                    self.ops_fwd.append(('alias', ind, layers[0]))
+                else:
+                    out = _Act(torch.empty(B * h * w * c, **f32), 0, c, h, w, c)
+                    self.acts[ind] = out
+                    self.ops_fwd.append(('concat', ind, layers, srcs, out))
+                prev = self.acts[ind]
+            else:  # region / cost: not executed in forward (darknet.py:119-127)
+                self.acts[ind] = prev
+        self.wpack = torch.empty(max(wsz, 1), **f32)
+        self.dpack = torch.empty(max(dsz, 1), **f32)
+        self.gpack = torch.empty(max(wsz, 1), **f32)   # packed filter gradients (zeroed each backward)
+        self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
+        self.wversion = {}
+        self.generation = 0
+        self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
+        self.out_act = self.acts[self.last]
+        self.consumed = False
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training):
+        B, H, W = self.B, self.H, self.W
+        st = torch.cuda.current_stream().cuda_stream
+        call = _lib.call
+        call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
+        for op in self.ops_fwd:
+            kind = op[0]
+            if kind == 'conv':
+                cs = op[1]
+                wt = cs.conv.weight
+                # eval: repack only when the parameter changed (in-place updates bump _version; load_weights
+                # invalidates explicitly); training: weights change every step, always repack
+                key = (wt.data_ptr(), wt._version)
+                if training or self.wversion.get(cs.ind) != key:
+                    call('ssp_repack_fwd', wt.data_ptr(), _ptr(self.wpack, cs.woff), cs.cout, cs.cin, cs.cinp, cs.k, st)
+                    self.wversion[cs.ind] = key
+                bias = cs.conv.bias.data_ptr() if cs.conv.bias is not None else None
+                use_stats = cs.bn and training
+                call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(), bias,
+                     cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
+                     cs.k, 0, st)
+                v = cs.vec
+                if cs.bn:
+                    bn = cs.bnm
+                    if training:
+                        call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
+                             bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                             bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
+                             v[2].data_ptr(), v[3].data_ptr(), st)
+                    else:
+                        call('ssp_bn_eval_prepare', cs.cout, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS, v[0].data_ptr(),
+                             v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
+                if cs.needs_act:
+                    call('ssp_bn_act_fwd', cs.raw.data_ptr(), cs.ldraw, cs.out.ptr, cs.out.ld, v[2].data_ptr(),
+                         v[3].data_ptr(), cs.coutp, B, cs.H, cs.W, 1 if cs.pool else 0, cs.slope, st)
+            elif kind == 'maxpool':
+                _, ind, src, out = op
+                call('ssp_maxpool_fwd', src.ptr, src.ld, out.ptr, out.ld, _pad4(src.C), B, src.H, src.W, st)
+            elif kind == 'reorg':
+                _, ind, src, out = op
+                call('ssp_reorg', src.ptr, src.ld, out.ptr, out.ld, src.C, B, src.H, src.W, 0, 0, st)
+            elif kind == 'concat':
+                _, ind, layers, srcs, out = op
+                off = 0
+                for s in srcs:
+                    call('ssp_copy_channels', s.ptr, s.ld, _ptr(out.t, off), out.ld, s.C, B * s.H * s.W, 0, st)
+                    off += s.C
+        o = self.out_act
+        y = torch.empty(B, o.C, o.H, o.W, dtype=torch.float32, device=self.device)
+        call('ssp_nhwc_to_nchw', o.ptr, y.data_ptr(), B, o.C, o.H, o.W, o.ld, st)
+        self.consumed = False
+        self.was_training = training
+        self.generation += 1
+        return y
+
+    # ------------------------------------------------------------------ backward
+    def _grad_buf(self, ind, like):
+        g = self.grads.get(ind)
+        if g is None:
+            g = _Act(torch.empty(self.B * like.H * like.W * like.ld, dtype=torch.float32, device=self.device), 0,
+                     like.C, like.H, like.W, like.ld)
+            self.grads[ind] = g
+        return g
+
+    def backward(self, grad_out):
+        """grad_out: (B, C, h, w) NCHW.  Returns {param tensor id: grad tensor}."""
+        if self.consumed:
+            raise RuntimeError("Darknet backward called twice on the same forward: the HIP path rewrites the saved "
+                               "conv outputs in place (no retain_graph support)")
+        self.consumed = True
+        B = self.B
+        st = torch.cuda.current_stream().cuda_stream
+        call = _lib.call
+        blocks = self.net.blocks
+        o = self.out_act
+        written = set()
+        g_last = self._grad_buf(self.last, o)
+        call('ssp_nchw_to_nhwc', grad_out.data_ptr(), g_last.ptr, B, o.C, o.H, o.W, o.C, o.ld, st)
+        if o.ld > o.C:
+            raise NotImplementedError("network output channels must be a multiple of 4")
+        written.add(self.last)
+        self.gpack.zero_()
+        out_grads = {}
+        training = self.was_training
+
+        def producer_of(act):
+            for i, a in enumerate(self.acts):
+                if a is act:
+                    return i
+            return None
+
+        for ind in range(self.nl - 1, -1, -1):
+            block = blocks[ind + 1]
+            t = block['type']
+            if t in ('region', 'cost'):
+                continue
+            if t == 'maxpool' and ind in self.fused_pool:
+                continue  # handled by the conv block that owns it
+            if t == 'convolutional':
+                cs = self.convs[ind]
+                oind = ind + 1 if cs.pool else ind
+                if oind not in written:
+                    continue
+                g = self.grads[oind]
+                v = cs.vec
+                if cs.needs_act:
+                    call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
+                         v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
+                         1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, self.bn_partial.data_ptr(),
+                         v[6].data_ptr(), v[7].data_ptr(), v[4].data_ptr(), v[5].data_ptr(), st)
+                    dy_ptr, dy_ld = cs.raw.data_ptr(), cs.ldraw
+                    if cs.bn:
+                        out_grads[id(cs.bnm.weight)] = v[6][:cs.cout].clone()
+                        out_grads[id(cs.bnm.bias)] = v[7][:cs.cout].clone()
+                else:
+                    dy_ptr, dy_ld = g.ptr, g.ld
+                if cs.conv.bias is not None:
+                    db = torch.empty(cs.cout, dtype=torch.float32, device=self.device)
+                    call('ssp_colsum', dy_ptr, dy_ld, cs.M, cs.cout, db.data_ptr(), st)
+                    out_grads[id(cs.conv.bias)] = db
+                call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp, cs.cout,
+                     dy_ld, cs.inp.ld, cs.k, st)
+                gw = torch.empty_like(cs.conv.weight)
+                call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st)
+                out_grads[id(cs.conv.weight)] = gw
+                if not cs.first:
+                    wt = cs.conv.weight
+                    call('ssp_repack_dgrad', wt.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp,
+                         cs.k, st)
+                    src = producer_of(cs.inp)
+                    gin = self._grad_buf(src, cs.inp)
+                    call('ssp_conv_dgrad', dy_ptr, _ptr(self.dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
+                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, st)
+                    written.add(src)
+            elif t == 'maxpool':
+                if ind not in written:
+                    continue
+                op = [o_ for o_ in self.ops_fwd if o_[0] == 'maxpool' and o_[1] == ind][0]
+                _, _, src, out = op
+                sind = producer_of(src)
+                gin = self._grad_buf(sind, src)
+                g = self.grads[ind]
+                call('ssp_maxpool_bwd', src.ptr, src.ld, g.ptr, g.ld, gin.ptr, gin.ld, _pad4(src.C), B, src.H, src.W,
+                     1 if sind in written else 0, st)
+                written.add(sind)
+            elif t == 'reorg':
+                if ind not in written:
+                    continue
+                op = [o_ for o_ in self.ops_fwd if o_[0] == 'reorg' and o_[1] == ind][0]
+                _, _, src, out = op
+                sind = producer_of(src)
+                gin = self._grad_buf(sind, src)
+                g = self.grads[ind]
+                call('ssp_reorg', g.ptr, g.ld, gin.ptr, gin.ld, src.C, B, src.H, src.W, 1,
+                     1 if sind in written else 0, st)
+                written.add(sind)
+            elif t == 'route':
+                if ind not in written:
+                    continue
+                layers = resolve_layers(block['layers'], ind)
+                g = self.grads[ind]
+                off = 0
+                for l in layers:
+                    a = self.acts[l]
+                    src = producer_of(a)
+                    gin = self._grad_buf(src, a)
+                    if gin is not g:
+                        call('ssp_copy_channels', _ptr(g.t, g.off + off), g.ld, gin.ptr, gin.ld, a.C, B * a.H * a.W,
+                             1 if src in written else 0, st)
+                    written.add(src)
+                    off += a.C
+        return out_grads
+
+
+class _DarknetFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are sequences of HIP launches."""
+
+    @staticmethod
+    def forward(ctx, plan, training, x, *params):
+        ctx.plan = plan
+        ctx.params = params
+        y = plan.forward(x, training)
+        ctx.generation = plan.generation
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("Darknet backward after a newer forward on the same input shape: the plan's saved "
+                               "activations were overwritten")
+        grads = plan.backward(grad_out.contiguous())
+        res = [None, None, None]
+        for p in ctx.params:
+            res.append(grads.get(id(p)))
+        return tuple(res)

@@ -1,0 +1,114 @@
+"""RegionLoss on one fused HIP kernel - host-side mirror of the reference's region_loss.py.
+
+Same surface as /root/reference/region_loss.py:80-175: RegionLoss(num_keypoints=9, num_classes=1, anchors=[],
+num_anchors=1, pretrain_num_epochs=15) with mutable attributes coord_scale / noobject_scale / object_scale /
+class_scale / thresh / seen / pretrain_num_epochs (and anchors / anchor_step / iter poked from outside,
+darknet.py:231-243, train.py:341); forward(output, target, epoch) -> 0-dim loss tensor supporting .backward()
+and .data, and printing the reference's per-iteration status line (region_loss.py:173).
+
+The reference moves every prediction to the host, builds targets in Python loops (build_targets,
+region_loss.py:9-78) and uploads 23 mask/target tensors.  Here ssp_region_loss does decode + targets + masks +
+loss + dL/d(output) in one launch per call; the only host traffic is the (<= 269 KB) label upload and - when
+`verbose` - one 32-byte read of the scalars for the status line.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _RegionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, mod, target, epoch):
+        out = output.detach()
+        if not out.is_cuda:
+            raise RuntimeError("RegionLoss runs on the MI355X HIP kernel only: got a %s tensor (no CPU fallback)" % out.device)
+        out = out.to(torch.float32).contiguous()
+        nB, nH, nW = out.size(0), out.size(2), out.size(3)
+        nA, nC, K = mod.num_anchors, mod.num_classes, mod.num_keypoints
+        if out.size(1) != nA * (2 * K + 1 + nC):
+            raise ValueError("output has %d channels, expected num_anchors*(2*num_keypoints+1+num_classes) = %d"
+                             % (out.size(1), nA * (2 * K + 1 + nC)))
+        tgt = target.detach()
+        if tgt.dtype not in (torch.float32, torch.float64):
+            tgt = tgt.to(torch.float32)
+        tgt = tgt.to(out.device).contiguous().view(nB, -1)
+        if tgt.size(1) != 50 * (2 * K + 3):
+            raise ValueError("target must hold 50 x (2*num_keypoints+3) numbers per image, got %d" % tgt.size(1))
+        grad = torch.empty_like(out)
+        partials = torch.empty(nB * 8, dtype=torch.float32, device=out.device)
+        stats = torch.empty(8, dtype=torch.float32, device=out.device)
+        anchors = None
+        if mod._multi:
+            anchors = torch.tensor([float(a) for a in mod.anchors], dtype=torch.float32, device=out.device)
+            step = len(mod.anchors) // nA
+        else:
+            step = 0
+        conf_on = 1 if epoch > mod.pretrain_num_epochs else 0
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.call('ssp_region_loss', out.data_ptr(), tgt.data_ptr(), 1 if tgt.dtype == torch.float64 else 0,
+                  grad.data_ptr(), partials.data_ptr(), stats.data_ptr(), nB, nA, nC, nH, nW, K,
+                  float(mod.noobject_scale), float(mod.object_scale), float(mod.coord_scale), float(mod.class_scale),
+                  float(mod.thresh), conf_on, 1 if mod._multi else 0,
+                  anchors.data_ptr() if anchors is not None else None, step, st)
+        ctx.save_for_backward(grad)
+        mod._last_stats = stats
+        return stats[4].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+class _RegionLossBase(nn.Module):
+    _multi = False
+
+    def __init__(self, num_keypoints, num_classes, anchors, num_anchors, pretrain_num_epochs):
+        super(_RegionLossBase, self).__init__()
+        self.num_classes = num_classes
+        self.anchors = anchors
+        self.num_anchors = num_anchors
+        self.anchor_step = len(anchors) // num_anchors if num_anchors else 0
+        self.num_keypoints = num_keypoints
+        self.coord_scale = 1
+        self.noobject_scale = 1
+        self.object_scale = 5
+        self.class_scale = 1
+        self.thresh = 0.6
+        self.seen = 0
+        self.pretrain_num_epochs = pretrain_num_epochs
+        self.verbose = True      # print the reference's status line (one 32-byte device read per call)
+        self._last_stats = None
+
+    def last_stats(self):
+        """Device tensor [loss_x, loss_y, loss_conf, loss_cls, total, nGT, nCorrect, nProposals] of the last call."""
+        return self._last_stats
+
+    def forward(self, output, target, epoch):
+        loss = _RegionLossFn.apply(output, self, target, epoch)
+        if self.verbose:
+            s = self._last_stats.tolist()
+            if self._multi:
+                print('%d: nGT %d, recall %d, proposals %d, loss: x %f, y %f, conf %f, cls %f, total %f' %
+                      (self.seen, int(s[5]), int(s[6]), int(s[7]), s[0], s[1], s[2], s[3], s[4]))
+            else:
+                print('%d: nGT %d, recall %d, proposals %d, loss: x %f, y %f, conf %f, total %f' %
+                      (self.seen, int(s[5]), int(s[6]), int(s[7]), s[0], s[1], s[2], s[4]))
+        return loss
+
+
+class RegionLoss(_RegionLossBase):
+    """Single-object loss (region_loss.py:80-175): one trivial anchor, no class term."""
+    _multi = False
+
+    def __init__(self, num_keypoints=9, num_classes=1, anchors=[], num_anchors=1, pretrain_num_epochs=15):
+        super(RegionLoss, self).__init__(num_keypoints, num_classes, anchors, num_anchors, pretrain_num_epochs)
+
+
+class RegionLossMulti(_RegionLossBase):
+    """Multi-object loss (multi_obj_pose_estimation/region_loss_multi.py:94-189): anchor pick by IoU, class CE."""
+    _multi = True
+
+    def __init__(self, num_keypoints=9, num_classes=13, anchors=[], num_anchors=5, pretrain_num_epochs=15):
+        super(RegionLossMulti, self).__init__(num_keypoints, num_classes, anchors, num_anchors, pretrain_num_epochs)

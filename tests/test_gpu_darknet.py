@@ -1,0 +1,133 @@
+"""End-to-end: Darknet on the HIP plan vs golden outputs of the reference Darknet (CPU) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLD, ROOT, clone_state, gold, golden_input, load_state_into, make_targets, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _build(cfgfile, seed):
+    from oracle.darknet_ref import seeded_state
+    from singleshotpose_amd.darknet import Darknet
+    model = Darknet(cfgfile)
+    state = seeded_state(model.blocks, seed)
+    load_state_into(model, model.blocks, state)
+    return model.cuda(), state
+
+
+def _check(cfgfile, tag, B, H, W, seed, with_grad):
+    g = gold('darknet_%s.npz' % tag)
+    model, state = _build(cfgfile, seed)
+    x = torch.from_numpy(golden_input(g, B, H, W)).cuda()
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    assert tuple(y.shape) == tuple(g['y_eval'].shape) and y.is_contiguous()
+    assert rel_err(y.cpu().numpy(), g['y_eval']) < TOL
+    if not with_grad:
+        return
+    model.train()
+    y = model(x)
+    assert rel_err(y.detach().cpu().numpy(), g['y_train']) < TOL
+    (y * torch.from_numpy(g['probe']).cuda()).sum().backward()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        gr = p.grad.detach().cpu().numpy()
+        ref_norm = float(g['gnorm/' + n][0])
+        got_norm = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+        assert abs(got_norm - ref_norm) <= 3e-4 * ref_norm + 1e-7, (n, got_norm, ref_norm)
+        if 'grad/' + n in g.files:
+            e = rel_err(gr, g['grad/' + n])
+        else:
+            sl = gr.reshape(-1)[:: max(1, gr.size // 512)][:512]
+            e = rel_err(sl, g['gslice/' + n])
+        worst = max(worst, e)
+        assert e < 3e-4, (n, e)
+    for n, b in model.named_buffers():
+        if 'running' in n:
+            np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5)
+
+
+def test_tiny_matches_reference():
+    _check(os.path.join(GOLD, 'tiny-pose.cfg'), 'tiny', 2, 96, 96, 5, True)
+
+
+def test_full_eval_matches_reference():
+    _check(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 'full_eval', 1, 416, 416, 6, False)
+
+
+def test_full_train_matches_reference():
+    _check(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 'full_train', 2, 416, 416, 7, True)
+
+
+def test_layerwise_vs_oracle_other_resolution():
+    """Multi-scale shapes (dataset.py:66-90 draws 224..832): tiny net at 160x160 (test size) against the oracle."""
+    from oracle.darknet_ref import forward_ref
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 9)
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.uniform(0, 1, (3, 3, 160, 160)).astype(np.float32))
+    model.eval()
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+        ref = forward_ref(model.blocks, clone_state(state), x, training=False)
+    assert rel_err(y.numpy(), ref.numpy()) < TOL
+
+
+def test_train_step_with_region_loss_and_sgd():
+    """The train.py inner loop (train.py:83-106): forward, RegionLoss, backward, SGD step - vs the same on the oracle."""
+    from oracle.darknet_ref import forward_ref
+    from oracle.region_loss_ref import region_loss_ref
+    from singleshotpose_amd.region_loss import RegionLoss
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 12)
+    rs = np.random.RandomState(4)
+    B = 4
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, 96, 96)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [1] * B))
+    crit = RegionLoss()
+    crit.verbose = False
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3 / B, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    model.train()
+    opt.zero_grad()
+    out = model(x.cuda())
+    loss = crit(out, tgt, 20)
+    loss.backward()
+    # oracle
+    st = clone_state(state, requires_grad=True)
+    y = forward_ref(model.blocks, st, x, training=True)
+    r = region_loss_ref(y.detach(), tgt, 20)
+    y.backward(r['grad'])
+    assert abs(float(loss) - r['loss']) <= TOL * abs(r['loss'])
+    for ind, e in enumerate(st):
+        if e is None:
+            continue
+        seq = model.models[ind]
+        assert rel_err(seq[0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 3e-4, ind
+    opt.step()
+    # weights changed -> next forward must see the new filters (repack is not stale)
+    out2 = model(x.cuda())
+    assert not torch.equal(out2, out)
+
+
+def test_weights_round_trip_and_module_tree(tmp_path):
+    from singleshotpose_amd.darknet import Darknet
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 21)
+    p1, p2 = str(tmp_path / 'a.weights'), str(tmp_path / 'b.weights')
+    model.seen = 1234
+    model.save_weights(p1)
+    m2 = Darknet(os.path.join(GOLD, 'tiny-pose.cfg'))
+    m2.load_weights(p1)
+    assert int(m2.seen) == 1234
+    m2.save_weights(p2)
+    assert open(p1, 'rb').read() == open(p2, 'rb').read()
+
+
+def test_cpu_input_raises():
+    from singleshotpose_amd.darknet import Darknet
+    m = Darknet(os.path.join(GOLD, 'tiny-pose.cfg'))
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(torch.zeros(1, 3, 96, 96))

@@ -1,0 +1,269 @@
+"""Per-kernel parity through the C ABI (libssp_hip.so) against PyTorch-CPU fp32 references of the same op.
+
+Tolerance: SURVEY.md section 8 / BASELINE.json: bit-exact for index-only kernels (reorg, route copy, repack, max-pool
+selection), max|a-b|/max|b| <= 1e-4 for fp32 arithmetic.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _imports():
+    import gpu_util as G
+    from singleshotpose_amd import _lib
+    return G, _lib
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, R, ldin_extra, ldout_extra, bias
+    (2, 13, 13, 64, 128, 3, 0, 0, False),
+    (1, 20, 24, 3, 32, 3, 0, 0, False),      # first layer: Cin 3 padded to 4, BK=4 path, 256x32 tile
+    (2, 10, 12, 128, 64, 1, 0, 0, False),    # 256x64 tile
+    (3, 7, 9, 32, 20, 1, 0, 0, True),        # head: bias, ragged Cout
+    (2, 13, 13, 48, 160, 3, 16, 32, False),  # channel slices of wider buffers; Cout not a tile multiple
+    (1, 26, 26, 20, 1024, 3, 0, 0, False),   # K chunk of 4 (Cin % 16 != 0), many N tiles
+    (5, 13, 13, 256, 256, 3, 0, 0, False),   # several M tiles + ragged M
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,R,xin,xout,bias", CONV_CASES)
+def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
+    G, _lib = _imports()
+    rs = np.random.RandomState(Cin * 7 + Cout)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, R, R)) / np.sqrt(Cin * R * R)).astype(np.float32))
+    bvec = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32)) if bias else None
+    ref = F.conv2d(x, w, bvec, padding=R // 2)
+    cinp = (Cin + 3) // 4 * 4
+    xp = torch.zeros(B, cinp, H, W)
+    xp[:, :Cin] = x
+    ldin, ldout = cinp + xin, Cout + xout
+    xin_off, xout_off = (xin // 2) // 4 * 4, xout // 2
+    xd = G.to_nhwc(xp, ldin, xin_off)
+    wd = G.pack_fwd(w, cinp)
+    out = torch.full((B * H * W, ldout), float('nan'), dtype=torch.float32, device=G.dev())
+    bd = bvec.to(G.dev()) if bias else None
+    tile_m = _lib.query('ssp_conv_stats_tile_m', Cout)
+    ntile = (B * H * W + tile_m - 1) // tile_m
+    stats = torch.zeros(ntile * Cout * 2, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
+              stats.data_ptr(), B, H, W, cinp, Cout, ldin, ldout, R, 0, G.stream())
+    torch.cuda.synchronize()
+    got = G.from_nhwc(out, B, Cout, H, W, xout_off)
+    assert rel_err(got.numpy(), ref.numpy()) < TOL
+    # untouched columns stay NaN: the kernel writes only its channel slice
+    if xout:
+        o = out.cpu()
+        assert torch.isnan(o[:, :xout_off]).all() and torch.isnan(o[:, xout_off + Cout:]).all()
+    # accumulate mode
+    _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
+              None, B, H, W, cinp, Cout, ldin, ldout, R, 1, G.stream())
+    torch.cuda.synchronize()
+    got2 = G.from_nhwc(out, B, Cout, H, W, xout_off)
+    assert rel_err(got2.numpy(), (2 * ref).numpy()) < TOL
+
+    # BatchNorm statistics from the epilogue partials (bias-free raw output)
+    if not bias:
+        M = B * H * W
+        vec = torch.zeros(4, Cout, dtype=torch.float32, device=G.dev())
+        gamma = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+        beta = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
+        rm = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
+        rv = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+        gd, bd2, rmd, rvd = gamma.to(G.dev()), beta.to(G.dev()), rm.clone().to(G.dev()), rv.clone().to(G.dev())
+        _lib.call('ssp_bn_fwd_finalize', stats.data_ptr(), ntile, tile_m, M, Cout, gd.data_ptr(), bd2.data_ptr(),
+                  rmd.data_ptr(), rvd.data_ptr(), 0.1, 1e-4, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                  vec[3].data_ptr(), G.stream())
+        torch.cuda.synchronize()
+        r64 = ref.double()
+        mean = r64.mean(dim=(0, 2, 3))
+        var = r64.var(dim=(0, 2, 3), unbiased=False)
+        np.testing.assert_allclose(vec[0].cpu().numpy(), mean.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(vec[1].cpu().numpy(), (1 / torch.sqrt(var + 1e-4)).numpy(), rtol=1e-4)
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        F.batch_norm(ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-4)
+        np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rvd.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+GRAD_CASES = [
+    (2, 13, 13, 64, 128, 3),
+    (1, 20, 24, 3, 32, 3),      # first layer (wgrad only)
+    (2, 10, 12, 128, 64, 1),
+    (3, 7, 9, 32, 20, 1),       # head: dY with 20 channels
+    (2, 12, 12, 32, 64, 3),     # 64x32 wgrad tile with in-workgroup K split
+    (4, 13, 13, 256, 256, 3),
+    (2, 26, 26, 512, 64, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,R", GRAD_CASES)
+def test_conv_dgrad_wgrad(B, H, W, Cin, Cout, R):
+    G, _lib = _imports()
+    rs = np.random.RandomState(Cin * 3 + Cout + R)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, R, R)) / np.sqrt(Cin * R * R)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32))
+    F.conv2d(x, w, None, padding=R // 2).backward(dy)
+    cinp, coutp = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xp = torch.zeros(B, cinp, H, W)
+    xp[:, :Cin] = x.detach()
+    xd = G.to_nhwc(xp)
+    dyp = torch.zeros(B, coutp, H, W)
+    dyp[:, :Cout] = dy
+    dyd = G.to_nhwc(dyp)
+    # wgrad
+    dwp = torch.zeros(Cout * R * R * cinp, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_conv_wgrad', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, cinp, Cout, coutp, cinp, R, G.stream())
+    gw = torch.empty(Cout, Cin, R, R, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_unpack_grad', dwp.data_ptr(), gw.data_ptr(), Cout, Cin, cinp, R, G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(gw.cpu().numpy(), w.grad.numpy()) < TOL
+    # dgrad
+    if Cin % 4 == 0:
+        wd = G.pack_dgrad(w.detach(), coutp)
+        dx = torch.full((B * H * W, Cin), float('nan'), dtype=torch.float32, device=G.dev())
+        _lib.call('ssp_conv_dgrad', dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin, coutp, Cin, R, 0, G.stream())
+        torch.cuda.synchronize()
+        assert rel_err(G.from_nhwc(dx, B, Cin, H, W).numpy(), x.grad.numpy()) < TOL
+
+
+def test_repack_bit_exact():
+    G, _lib = _imports()
+    rs = np.random.RandomState(0)
+    for (co, ci, k, cip) in [(20, 12, 3, 12), (32, 3, 3, 4), (70, 100, 1, 100), (33, 65, 3, 68)]:
+        w = torch.from_numpy(rs.standard_normal((co, ci, k, k)).astype(np.float32))
+        got = G.pack_fwd(w, cip).cpu().reshape(co, k * k, cip)
+        ref = torch.zeros(co, k * k, cip)
+        ref[:, :, :ci] = w.reshape(co, ci, k * k).permute(0, 2, 1)
+        assert torch.equal(got, ref)
+        back = torch.empty(co, ci, k, k, dtype=torch.float32, device=G.dev())
+        _lib.call('ssp_unpack_grad', G.pack_fwd(w, cip).data_ptr(), back.data_ptr(), co, ci, cip, k, G.stream())
+        assert torch.equal(back.cpu(), w)
+        cop = (co + 3) // 4 * 4
+        gotd = G.pack_dgrad(w, cop).cpu().reshape(ci, k * k, cop)
+        refd = torch.zeros(ci, k * k, cop)
+        refd[:, :, :co] = torch.flip(w.reshape(co, ci, k * k), dims=[2]).permute(1, 2, 0)
+        assert torch.equal(gotd, refd)
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+@pytest.mark.parametrize("C,B,H,W", [(32, 2, 8, 12), (1024, 1, 4, 6), (20, 3, 6, 6), (64, 5, 26, 26)])
+def test_bn_act_fwd_bwd(C, B, H, W, pool):
+    G, _lib = _imports()
+    rs = np.random.RandomState(C + pool)
+    x = torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32) * 2 + 0.3).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy((rs.standard_normal(C) * 0.3).astype(np.float32)).requires_grad_(True)
+    y = F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-4)
+    y = F.leaky_relu(y, 0.1)
+    if pool:
+        y = F.max_pool2d(y, 2, 2)
+    g = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(g)
+    xd = G.to_nhwc(x.detach())
+    M = B * H * W
+    x64 = x.detach().double()
+    mean = x64.mean(dim=(0, 2, 3))
+    var = x64.var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-4)
+    vec = torch.zeros(8, C, dtype=torch.float32, device=G.dev())
+    vec[0] = mean.float().to(G.dev())
+    vec[1] = invstd.float().to(G.dev())
+    vec[2] = (gamma.detach() * invstd.float()).to(G.dev())
+    vec[3] = (beta.detach() - mean.float() * gamma.detach() * invstd.float()).to(G.dev())
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty(B * Ho * Wo, C, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_bn_act_fwd', xd.data_ptr(), C, out.data_ptr(), C, vec[2].data_ptr(), vec[3].data_ptr(), C, B, H, W, pool, 0.1, G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(out, B, C, Ho, Wo).numpy(), y.detach().numpy()) < TOL
+    gd = G.to_nhwc(g)
+    partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * C * 2, dtype=torch.float32, device=G.dev())
+    dx = torch.empty_like(xd)
+    _lib.call('ssp_bn_act_bwd', xd.data_ptr(), C, gd.data_ptr(), C, dx.data_ptr(), C, vec[2].data_ptr(), vec[3].data_ptr(),
+              vec[0].data_ptr(), vec[1].data_ptr(), C, B, H, W, pool, 0.1, 1, partial.data_ptr(), vec[6].data_ptr(),
+              vec[7].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(dx, B, C, H, W).numpy(), x.grad.numpy()) < 2e-4
+    assert rel_err(vec[6].cpu().numpy(), gamma.grad.numpy()) < 2e-4
+    assert rel_err(vec[7].cpu().numpy(), beta.grad.numpy()) < 2e-4
+    # in-place form (dx aliases x), as the engine uses it
+    x2 = xd.clone()
+    _lib.call('ssp_bn_act_bwd', x2.data_ptr(), C, gd.data_ptr(), C, x2.data_ptr(), C, vec[2].data_ptr(), vec[3].data_ptr(),
+              vec[0].data_ptr(), vec[1].data_ptr(), C, B, H, W, pool, 0.1, 1, partial.data_ptr(), vec[6].data_ptr(),
+              vec[7].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(x2, dx)
+
+
+def test_reorg_route_maxpool_bit_exact(golden_dir):
+    G, _lib = _imports()
+    from helpers import gold
+    g = gold('reorg.npz')
+    x = torch.from_numpy(g['x'])
+    B, C, H, W = x.shape
+    xd = G.to_nhwc(x, ld=C + 8, off=4)
+    out = torch.full((B * (H // 2) * (W // 2), 4 * C + 12), float('nan'), dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_reorg', G.p(xd, 4), C + 8, G.p(out, 8), 4 * C + 12, C, B, H, W, 0, 0, G.stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(G.from_nhwc(out, B, 4 * C, H // 2, W // 2, 8).numpy(), g['y'])   # golden from the reference's Reorg
+    # backward = inverse permutation
+    back = torch.zeros(B * H * W, C, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_reorg', G.p(out, 8), 4 * C + 12, back.data_ptr(), C, C, B, H, W, 1, 0, G.stream())
+    assert torch.equal(G.from_nhwc(back, B, C, H, W), x)
+    _lib.call('ssp_reorg', G.p(out, 8), 4 * C + 12, back.data_ptr(), C, C, B, H, W, 1, 1, G.stream())
+    assert torch.equal(G.from_nhwc(back, B, C, H, W), 2 * x)
+    # route concat = two slice copies
+    rs = np.random.RandomState(1)
+    a = torch.from_numpy(rs.standard_normal((2, 8, 5, 5)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal((2, 12, 5, 5)).astype(np.float32))
+    ad, bd = G.to_nhwc(a), G.to_nhwc(b)
+    cat = torch.empty(2 * 25, 20, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_copy_channels', ad.data_ptr(), 8, cat.data_ptr(), 20, 8, 50, 0, G.stream())
+    _lib.call('ssp_copy_channels', bd.data_ptr(), 12, G.p(cat, 8), 20, 12, 50, 0, G.stream())
+    assert torch.equal(G.from_nhwc(cat, 2, 20, 5, 5), torch.cat((a, b), 1))
+    # layout round trip NCHW <-> NHWC
+    xn = torch.from_numpy(rs.standard_normal((2, 3, 6, 8)).astype(np.float32)).to(G.dev())
+    nh = torch.empty(2 * 48 * 4, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_nchw_to_nhwc', xn.data_ptr(), nh.data_ptr(), 2, 3, 6, 8, 4, 4, G.stream())
+    ref = torch.zeros(2, 6, 8, 4)
+    ref[..., :3] = xn.cpu().permute(0, 2, 3, 1)
+    assert torch.equal(nh.cpu().view(2, 6, 8, 4), ref)
+    xb = torch.empty(2, 3, 6, 8, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_nhwc_to_nchw', nh.data_ptr(), xb.data_ptr(), 2, 3, 6, 8, 4, G.stream())
+    assert torch.equal(xb, xn)
+    # max-pool fwd/bwd incl. ties (first maximum wins)
+    xm = torch.from_numpy(rs.randint(0, 3, (2, 8, 6, 6)).astype(np.float32)).requires_grad_(True)
+    ym = F.max_pool2d(xm, 2, 2)
+    gm = torch.from_numpy(rs.standard_normal(tuple(ym.shape)).astype(np.float32))
+    ym.backward(gm)
+    xmd, gmd = G.to_nhwc(xm.detach()), G.to_nhwc(gm)
+    ymd = torch.empty(2 * 9, 8, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_maxpool_fwd', xmd.data_ptr(), 8, ymd.data_ptr(), 8, 8, 2, 6, 6, G.stream())
+    assert torch.equal(G.from_nhwc(ymd, 2, 8, 3, 3), ym.detach())
+    dxm = torch.empty(2 * 36, 8, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_maxpool_bwd', xmd.data_ptr(), 8, gmd.data_ptr(), 8, dxm.data_ptr(), 8, 8, 2, 6, 6, 0, G.stream())
+    assert torch.equal(G.from_nhwc(dxm, 2, 8, 6, 6), xm.grad)
+
+
+def test_colsum():
+    G, _lib = _imports()
+    rs = np.random.RandomState(5)
+    g = torch.from_numpy(rs.standard_normal((1000, 20)).astype(np.float32))
+    gd = g.to(G.dev())
+    out = torch.empty(20, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_colsum', gd.data_ptr(), 20, 1000, 20, out.data_ptr(), G.stream())
+    np.testing.assert_allclose(out.cpu().numpy(), g.double().sum(0).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_error_reporting():
+    G, _lib = _imports()
+    with pytest.raises(_lib.SspError, match="1x1 and 3x3"):
+        _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, G.stream())
