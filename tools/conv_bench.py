@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Single-layer conv kernel timing through the C ABI (optimisation harness; GPU only).
+
+  python tools/conv_bench.py [--cases l2,l8,l18,l23,l29] [--iters 20] [--ops fwd,dgrad,wgrad] [--B 64]
+Prints TFLOP/s per (case, op) from torch.cuda events on the launch stream (median of iters).
+"""
+import argparse, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from singleshotpose_amd import _lib
+
+# name: (H, Cin, Cout, R) of yolo-pose.cfg layers at 416x416
+CASES = {
+    'l0': (416, 4, 32, 3), 'l2': (208, 32, 64, 3), 'l4': (104, 64, 128, 3), 'l5': (104, 128, 64, 1),
+    'l8': (52, 128, 256, 3), 'l9': (52, 256, 128, 1), 'l12': (26, 256, 512, 3), 'l13': (26, 512, 256, 1),
+    'l18': (13, 512, 1024, 3), 'l19': (13, 1024, 512, 1), 'l23': (13, 1024, 1024, 3), 'l29': (13, 1280, 1024, 3),
+    'l30': (13, 1024, 20, 1), 'l26': (26, 512, 64, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', default='l2,l4,l8,l12,l18,l23,l29')
+    ap.add_argument('--ops', default='fwd,dgrad,wgrad')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--B', type=int, default=64)
+    ap.add_argument('--opt', default='', help='name=value,... passed to ssp_set_option')
+    args = ap.parse_args()
+    for kv in filter(None, args.opt.split(',')):
+        k, v = kv.split('=')
+        _lib.call('ssp_set_option', k.encode(), int(v))
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.current_stream().cuda_stream
+    B = args.B
+    for name in args.cases.split(','):
+        H, Cin, Cout, R = CASES[name]
+        W = H
+        M = B * H * W
+        g = torch.Generator(device='cpu').manual_seed(1)
+        x = (torch.rand(M * Cin, generator=g) * 2 - 1).to(dev)
+        coutp = (Cout + 3) // 4 * 4
+        dy = (torch.rand(M * coutp, generator=g) * 2 - 1).to(dev)
+        w = (torch.rand(Cout * R * R * Cin, generator=g) * 2 - 1).to(dev) * 0.05
+        wd = (torch.rand(Cin * R * R * coutp, generator=g) * 2 - 1).to(dev) * 0.05
+        out = torch.empty(M * coutp, device=dev)
+        dx = torch.empty(M * Cin, device=dev)
+        dw = torch.zeros(Cout * R * R * Cin, device=dev)
+        tile_m = _lib.query('ssp_conv_stats_tile_m', Cout)
+        stats = torch.empty(((M + tile_m - 1) // tile_m) * Cout * 2, device=dev)
+        flop = 2.0 * M * Cout * R * R * Cin
+        fns = {
+            'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
+                                     B, H, W, Cin, Cout, Cin, coutp, R, 0, st),
+            'dgrad': lambda: _lib.call('ssp_conv_dgrad', dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin,
+                                       coutp, Cin, R, 0, st),
+            'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
+                                       coutp, Cin, R, st),
+        }
+        line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d |' % (name, H, Cin, Cout, R)
+        for op in args.ops.split(','):
+            if op == 'dgrad' and name == 'l0':
+                continue
+            fn = fns[op]
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            med = float(np.median(ts))
+            line += ' %s %7.1f us %6.1f TF |' % (op, med * 1e3, flop / (med * 1e-3) / 1e12)
+        print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
