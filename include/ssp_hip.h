@@ -22,15 +22,18 @@ extern "C" {
 
 const char* ssp_last_error(void);
 int ssp_abi_version(void);
+/* tuning knobs (kernel variant / tile selection); unknown names are an error.  Never changes results beyond fp32
+ * summation order. */
+int ssp_set_option(const char* name, int value);
 
 /* ---- convolution (stride 1, "same" padding, R = 1 or 3): nn.Conv2d at darknet.py:156,160 ------------------- */
 
 /* out[p][co] (+)= sum_{tap,ci} in[p + tap][ci] * wt[co][tap][ci]  (+ bias[co]);  wt from ssp_repack_fwd.
- * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(Cout))][Cout][2] per-tile (mean, M2) of the raw output,
+ * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(B,H,W,Cout))][Cout][2] per-tile (mean, M2) of the raw output,
  * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157). */
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
                  int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream);
-int ssp_conv_stats_tile_m(int Cout);
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cout);
 
 /* data gradient (autograd of nn.Conv2d, train.py:103): dx[p][ci] (+)= sum dy[p - tap][co] * w[co][ci][tap];
  * same contraction as ssp_conv_fwd with `wt` from ssp_repack_dgrad; Cout_dy = channels of dy (multiple of 4). */

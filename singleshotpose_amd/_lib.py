@@ -25,8 +25,9 @@ L = c_int64
 # name -> argtypes (all return int unless noted)
 _SIGS = {
     "ssp_abi_version": [],
+    "ssp_set_option": [c_char_p, I],
     "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "ssp_conv_stats_tile_m": [I],
+    "ssp_conv_stats_tile_m": [I, I, I, I],
     "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
     "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],

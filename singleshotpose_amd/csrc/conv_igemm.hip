@@ -18,6 +18,8 @@
 // (cdna_hip_programming.md section 3).  The k order inside a BK chunk is arbitrary as long as A and B
 // agree, so lane (i,h) reads VEC consecutive floats at column h*VEC of its LDS row with one
 // ds_read_b128/b64 and feeds them to VEC successive MFMAs.
+#include <type_traits>
+
 #include "ssp_common.h"
 
 struct ConvArgs {
@@ -29,6 +31,7 @@ struct ConvArgs {
   int H, W, Cin, Cout, ldin, ldout, R, M;
   int accumulate;     // out += result (second consumer of a routed activation in dgrad)
   int ntile_m, ntile_n;
+  int xcd_remap;
 };
 
 __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
@@ -42,7 +45,17 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+// ABL: 0 = product kernel; ablation bits for tools/conv_bench.py only (results are garbage): 1 no global loads in
+// the K loop, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no LDS stores
+//
+// Pipeline (per K chunk `it`, LDS ring of 3 slots, one barrier per chunk):
+//   registers (chunk it+2, loaded one chunk ago) -> LDS slot (it+2)%3 | global loads of chunk it+3 -> registers
+//   | MFMAs on chunk it (its first fragments were read during chunk it-1)
+//   | fragment reads of chunk it+1 (written + barrier-published one chunk ago) | barrier
+// so after a barrier the matrix cores restart from registers, and neither the LDS round trip nor the HBM/L2 latency of
+// a chunk sits between two MFMA blocks.  Loads are branch-free: out-of-image taps read a clamped address and are
+// zeroed with v_cndmask; rows/columns beyond M/Cout read row 0 / the last filter and are never stored.
+template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int LS = BK + 4;        // LDS row stride in floats (16-B aligned, conflict-free b128 reads)
@@ -54,15 +67,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int VEC = (BK >= 8) ? 4 : 2;
   constexpr int NQ = BK / (2 * VEC);
+  constexpr int SLOT = (BM + BN) * LS;   // floats per ring slot: A rows then B rows
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
   static_assert(NQ >= 1, "BK too small");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
-  float* As = smem;
-  float* Bs = smem + 2 * BM * LS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 * SLOT floats
 
   const int nwg = p.ntile_m * p.ntile_n;
-  const int lid = ssp_xcd_remap(blockIdx.x, nwg);
+  const int lid = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
   const int tile_n = lid % p.ntile_n, tile_m = lid / p.ntile_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -82,59 +94,90 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   for (int i = 0; i < APASS; ++i) {
     int row = lrow + i * RPP;
     int m = m0 + row;
-    if (row < BM && m < p.M) {
-      int x = m % p.W;
-      int t = m / p.W;
-      a_y[i] = t % p.H;
-      a_x[i] = x;
-      a_ptr[i] = p.in + (int64_t)m * p.ldin + lcol;
-    } else {
-      a_y[i] = -(1 << 20);
-      a_x[i] = 0;
-      a_ptr[i] = p.in;
-    }
+    if (m >= p.M) m = p.M - 1;   // clamped duplicate row: computed, never stored
+    int x = m % p.W;
+    int t = m / p.W;
+    a_y[i] = t % p.H;
+    a_x[i] = x;
+    a_ptr[i] = p.in + (int64_t)m * p.ldin + lcol;
   }
   const float* b_ptr[BPASS];
-  bool b_ok[BPASS];
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) {
-    int row = lrow + i * RPP;
-    int n = n0 + row;
-    b_ok[i] = (row < BN) && (n < p.Cout);
-    b_ptr[i] = b_ok[i] ? (p.wt + (int64_t)n * K + lcol) : p.wt;
+    int n = n0 + lrow + i * RPP;
+    if (n >= p.Cout) n = p.Cout - 1;
+    b_ptr[i] = p.wt + (int64_t)n * K + lcol;
   }
 
   f32x4 a_reg[APASS], b_reg[BPASS];
-  auto load_global = [&](int it) {
-    int tap = it / cpt;
-    int c0 = (it - tap * cpt) * BK;
-    int dy = tap / p.R - pad, dx = tap % p.R - pad;
-    int64_t shift = ((int64_t)dy * p.W + dx) * p.ldin + c0;
+  unsigned a_okmask = 0;   // bit i: pass i of the staged chunk is inside the image (applied at LDS-store time, so
+                           // the zeroing select does not pull the s_waitcnt for the loads in front of the MFMAs)
+  // K-chunk walker for the loader (chunks are visited in order; no per-chunk integer division)
+  int ld_c0 = 0, ld_dy = -pad, ld_dx = -pad;
+  int64_t ld_koff = 0;   // it * BK
+  auto load_global = [&](f32x4 (&a_reg)[APASS], f32x4 (&b_reg)[BPASS], unsigned& a_okmask) {
+    const int64_t shift = ((int64_t)ld_dy * p.W + ld_dx) * p.ldin + ld_c0;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      int yy = a_y[i] + ld_dy, xx = a_x[i] + ld_dx;
       bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift);
-      a_reg[i] = v;
+      a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (ok ? shift : (int64_t)ld_c0));
+      a_okmask = ok ? (a_okmask | (1u << i)) : (a_okmask & ~(1u << i));
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + ld_koff);
+    // advance; past the last chunk the walker re-reads the last filter columns / an out-of-window tap (harmless:
+    // those stagings land in a ring slot nobody reads), which keeps the K loop free of branches
+    ld_koff = min(ld_koff + BK, (int64_t)(K - BK));
+    ld_c0 += BK;
+    const bool wrap = ld_c0 == p.Cin;
+    ld_c0 = wrap ? 0 : ld_c0;
+    ld_dx += wrap ? 1 : 0;
+    const bool wrap2 = ld_dx > pad;
+    ld_dx = wrap2 ? -pad : ld_dx;
+    ld_dy += wrap2 ? 1 : 0;
+  };
+  auto store_lds = [&](int slot, const f32x4 (&a_reg)[APASS], const f32x4 (&b_reg)[BPASS], unsigned a_okmask) {
+    float* As = smem + slot * SLOT;
+    float* Bs = As + BM * LS;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      int row = lrow + i * RPP;
+      const bool ok = (a_okmask >> i) & 1u;
+      f32x4 v;
+      v[0] = ok ? a_reg[i][0] : 0.f; v[1] = ok ? a_reg[i][1] : 0.f;
+      v[2] = ok ? a_reg[i][2] : 0.f; v[3] = ok ? a_reg[i][3] : 0.f;
+      if (BM % RPP == 0 || row < BM) *reinterpret_cast<f32x4*>(As + row * LS + lcol) = v;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(b_ptr[i] + (int64_t)it * BK);
-      b_reg[i] = v;
+      int row = lrow + i * RPP;
+      if (BN % RPP == 0 || row < BN) *reinterpret_cast<f32x4*>(Bs + row * LS + lcol) = b_reg[i];
     }
   };
-  auto store_lds = [&](int buf) {
+  // fragment read: lane (i,h) takes VEC consecutive floats at column q*2*VEC + h*VEC of its row
+  auto read_frag = [&](int slot, int q, float (&fa)[TM][VEC], float (&fb)[TN][VEC]) {
+    const float* Ab = smem + slot * SLOT + (wm * WTM + li) * LS + lh * VEC + q * 2 * VEC;
+    const float* Bb = smem + slot * SLOT + (BM + wn * WTN + li) * LS + lh * VEC + q * 2 * VEC;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      int row = lrow + i * RPP;
-      if (row < BM) *reinterpret_cast<f32x4*>(As + (buf * BM + row) * LS + lcol) = a_reg[i];
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (VEC == 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LS);
+        fa[i][0] = t[0]; fa[i][1] = t[1]; fa[i][2] = t[2]; fa[i][3] = t[3];
+      } else {
+        f32x2 t = *reinterpret_cast<const f32x2*>(Ab + i * 32 * LS);
+        fa[i][0] = t[0]; fa[i][1] = t[1];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      int row = lrow + i * RPP;
-      if (row < BN) *reinterpret_cast<f32x4*>(Bs + (buf * BN + row) * LS + lcol) = b_reg[i];
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (VEC == 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LS);
+        fb[j][0] = t[0]; fb[j][1] = t[1]; fb[j][2] = t[2]; fb[j][3] = t[3];
+      } else {
+        f32x2 t = *reinterpret_cast<const f32x2*>(Bb + j * 32 * LS);
+        fb[j][0] = t[0]; fb[j][1] = t[1];
+      }
     }
   };
 
@@ -146,53 +189,79 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_global(0);
-  store_lds(0);
+  auto mma = [&](float (&fa)[TM][VEC], float (&fb)[TN][VEC]) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr ((ABL & 2) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(fa[i][e]), "v"(fb[j][e]));
+#endif
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+          }
+        }
+  };
+
+  // ---- prologue: chunks 0 and 1 into slots 0 and 1, first fragments into registers ----
+  {
+    // all three stagings are issued back to back (one memory round trip, not three); past the last chunk the walker
+    // re-reads in-bounds data that is never consumed
+    f32x4 a0[APASS], b0[BPASS], a1[APASS], b1[BPASS];
+    unsigned m0k = 0, m1k = 0;
+    load_global(a0, b0, m0k);
+    load_global(a1, b1, m1k);
+    load_global(a_reg, b_reg, a_okmask);   // chunk 2 stays in registers until the first loop iteration stores it
+    store_lds(0, a0, b0, m0k);
+    store_lds(1, a1, b1, m1k);
+  }
   __syncthreads();
+  float fa[2][TM][VEC], fb[2][TN][VEC];   // fragment double buffer; set (q & 1) holds sub-step q
+  read_frag(0, 0, fa[0], fb[0]);
 
+  int slot = 0;   // it % 3
   for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < niter) load_global(it + 1);  // in flight while the matrix cores work on `buf`
-
-    const float* Ab = As + (buf * BM + wm * WTM + li) * LS + lh * VEC;
-    const float* Bb = Bs + (buf * BN + wn * WTN + li) * LS + lh * VEC;
+    const int slot1 = (slot == 2) ? 0 : slot + 1;          // (it+1) % 3
+    const int slot2 = (slot1 == 2) ? 0 : slot1 + 1;        // (it+2) % 3
+    // Branch-free body (one basic block, so the scheduler can interleave loads / LDS traffic with the MFMAs): in
+    // the last two chunks the staging of "chunk it+2" and the fragment prefetch of "chunk it+1" are redundant
+    // re-reads whose results are never consumed.
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      float av[TM][VEC], bv[TN][VEC];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if constexpr (VEC == 4) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LS + q * 2 * VEC);
-          av[i][0] = t[0]; av[i][1] = t[1]; av[i][2] = t[2]; av[i][3] = t[3];
+      // fragments of the next sub-step (or of the next chunk) are fetched while this sub-step's MFMAs run
+      if constexpr ((ABL & 8) == 0) {
+        if (q + 1 < NQ) {
+          read_frag(slot, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
         } else {
-          f32x2 t = *reinterpret_cast<const f32x2*>(Ab + i * 32 * LS + q * 2 * VEC);
-          av[i][0] = t[0]; av[i][1] = t[1];
+          read_frag(slot1, 0, fa[NQ & 1], fb[NQ & 1]);
         }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (VEC == 4) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LS + q * 2 * VEC);
-          bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
-        } else {
-          f32x2 t = *reinterpret_cast<const f32x2*>(Bb + j * 32 * LS + q * 2 * VEC);
-          bv[j][0] = t[0]; bv[j][1] = t[1];
-        }
+      if (q == 0) {
+        if (!(ABL & 16)) store_lds(slot2, a_reg, b_reg, a_okmask);  // chunk it+2, loaded during the previous chunk's MFMAs -> its ring slot
+        if (!(ABL & 1)) load_global(a_reg, b_reg, a_okmask);    // chunk it+3 -> registers; has a whole chunk of MFMAs to land
       }
-#pragma unroll
-      for (int e = 0; e < VEC; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+      mma(fa[q & 1], fb[q & 1]);
     }
-
-    if (it + 1 < niter) store_lds(buf ^ 1);
-    __syncthreads();
+    if constexpr ((ABL & 4) == 0) __syncthreads();
+    if constexpr ((NQ & 1) != 0) {   // odd NQ: the prefetched q=0 fragments sit in set 1, move them to set 0
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fa[0][i][e] = fa[1][i][e];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fb[0][j][e] = fb[1][j][e];
+    }
+    slot = slot1;
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+  auto epilogue = [&](auto accum_tag) {
+  constexpr bool ACCUM = decltype(accum_tag)::value;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + li;
@@ -208,7 +277,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
         float v = acc[i][j][r] + bias;
         if (m < p.M && n_ok) {
           float* o = p.out + (int64_t)m * p.ldout + n;
-          if (p.accumulate) v += *o;
+          if constexpr (ACCUM) v += *o;
           *o = v;
           cnt += 1.f;
           sum += acc[i][j][r];
@@ -243,6 +312,19 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
       }
     }
   }
+  };
+  if constexpr ((ABL & 32) == 0) {
+    if (p.accumulate) epilogue(std::true_type{}); else epilogue(std::false_type{});
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));   // keep the accumulators (and the MFMAs feeding them) alive
+#endif
+      }
+  }
   if (p.stats != nullptr) {
     __syncthreads();
     for (int col = tid; col < BN; col += NT) {
@@ -261,22 +343,44 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
-static int launch_cfg(ConvArgs a, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
+static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
   dim3 grid(a.ntile_m * a.ntile_n), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK>), grid, block, 0, stream, a);
+  const int lds_bytes = 3 * (BM + BN) * (BK + 4) * 4 + extra_lds;
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, ABL>;
+  static int configured = 0;   // per instantiation
+  if (lds_bytes > configured) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      ssp_set_error("conv_igemm: cannot reserve %d bytes of LDS", lds_bytes);
+      return SSP_ERR_HIP;
+    }
+    configured = lds_bytes;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_igemm");
   return SSP_OK;
 }
 
-// Rows of the per-M-tile statistics buffer a forward launch will write (host sizes the workspace).
-int ssp_conv_tile_m(int Cout) { return Cout > 64 ? 128 : 256; }
+// Tile selection (shared by the launcher and by the host-side query that sizes the BN statistics workspace).
+// 128x128 is the workhorse; layers whose 128x128 grid would not fill the 512 resident-workgroup slots a few times over
+// (the 13x13 and 26x26 maps) use 64-row tiles to cut the last-wave imbalance; thin layers use 256-row tiles.
+static int select_bm(int M, int Cout) {
+  if (Cout > 64) {
+    const int64_t tiles128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
+    const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
+    if (variant == 20 || variant == 22) return 64;
+    if (variant == 0 && tiles128 <= 1400) return 64;
+    return 128;
+  }
+  return 256;
+}
+int ssp_conv_tile_m(int M, int Cout) { return select_bm(M, Cout); }
 
-int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats,
-                          int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate,
-                          int prof_kind, hipStream_t stream) {
+int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
+                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int prof_kind,
+                          hipStream_t stream) {
   SSP_CHECK_ARG(R == 1 || R == 3, "conv: only 1x1 and 3x3 filters are supported (got %d)", R);
   SSP_CHECK_ARG(Cin % 4 == 0 && Cin > 0, "conv: Cin must be a positive multiple of 4 (got %d)", Cin);
   SSP_CHECK_ARG(ldin % 4 == 0 && ldin >= Cin, "conv: ldin must be a multiple of 4 and >= Cin");
@@ -287,13 +391,38 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.in = in; a.wt = wt; a.out = out; a.bias = bias; a.stats = stats;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
+  a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   SspProfScope prof(prof_kind, stream, 2.0 * (double)a.M * Cout * (double)(R * R * Cin));
-  const bool k16 = (Cin % 16) == 0;
+  const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);   // experiments: tools/conv_bench.py --opt igemm_variant=N
+  const int bk = (Cin % 32 == 0 && (variant == 2 || variant == 4 || variant == 5)) ? 32 : ((Cin % 16 == 0) ? 16 : 4);
   if (Cout > 64) {
-    return k16 ? launch_cfg<128, 128, 2, 2, 16>(a, stream) : launch_cfg<128, 128, 2, 2, 4>(a, stream);
+    const int bm = select_bm(a.M, Cout);
+    switch (variant) {
+      case 3: if (bk >= 16) return launch_cfg<256, 128, 4, 2, 16>(a, stream); break;
+      case 4: if (bk == 32) return launch_cfg<128, 128, 2, 2, 32, 1>(a, stream); break;
+      case 5: if (bk == 32) return launch_cfg<128, 128, 2, 2, 32, 2>(a, stream); break;
+      case 10: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1>(a, stream); break;            // no loads
+      case 14: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16>(a, stream); break;  // MFMA only
+      case 17: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16 | 32>(a, stream); break;  // MFMA only, no epilogue
+      case 18: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 32>(a, stream); break;   // full loop, no epilogue
+      case 21: if (bk >= 16) return launch_cfg<128, 64, 2, 2, 16>(a, stream); break;
+      case 22: if (bk >= 16) return launch_cfg<64, 64, 2, 2, 16>(a, stream); break;
+      default: break;
+    }
+    if (bm == 64) {
+      if (bk >= 16) return launch_cfg<64, 128, 2, 2, 16>(a, stream);
+      return launch_cfg<64, 128, 2, 2, 4>(a, stream);
+    }
+    if (bk == 32) return launch_cfg<128, 128, 2, 2, 32>(a, stream);
+    if (bk == 16) return launch_cfg<128, 128, 2, 2, 16>(a, stream);
+    return launch_cfg<128, 128, 2, 2, 4>(a, stream);
   } else if (Cout > 32) {
-    return k16 ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
+    if (bk == 32) return launch_cfg<256, 64, 4, 1, 32>(a, stream);
+    if (bk == 16) return launch_cfg<256, 64, 4, 1, 16>(a, stream);
+    return launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else {
-    return k16 ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
+    if (bk == 32) return launch_cfg<256, 32, 4, 1, 32>(a, stream);
+    if (bk == 16) return launch_cfg<256, 32, 4, 1, 16>(a, stream);
+    return launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }
 }

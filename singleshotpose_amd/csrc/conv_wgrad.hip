@@ -23,6 +23,9 @@ struct WgradArgs {
   int ntile_co, ntile_ci, nsplit, chunk_m;
 };
 
+// Pipeline: as conv_igemm.hip - LDS ring of 3 slots, one barrier per staged chunk of RA pixel rows; the registers hold
+// chunk it+2 (loaded during the previous chunk's MFMAs), are written to slot (it+2)%3 at the top of the iteration and
+// immediately refilled with chunk it+3.  Loads are branch-free (clamped address, zeroed at LDS-store time).
 template <int BMO, int BNI, int WM, int WN, int WK>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
   static_assert(WM * WN * WK == 4, "256-thread workgroups");
@@ -32,11 +35,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int F4A = RA * BMO / 4, F4B = RA * BNI / 4;
   constexpr int APASS = (F4A + NT - 1) / NT, BPASS = (F4B + NT - 1) / NT;
+  constexpr int SLOT = RA * (BMO + BNI);
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * RA * (BMO + BNI)];
-  float* As = smem;                  // [2][RA][BMO]
-  float* Bs = smem + 2 * RA * BMO;   // [2][RA][BNI]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 * SLOT floats: per slot [RA][BMO] then [RA][BNI]
 
   const int taps = p.R * p.R;
   int bid = blockIdx.x;
@@ -52,6 +54,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
   const int m_begin = split * p.chunk_m;
   const int m_end = min(p.M, m_begin + p.chunk_m);
   const int niter = (m_end - m_begin + RA - 1) / RA;
+  if (niter <= 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid / (WM * WN);
@@ -59,54 +62,69 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
   const int wm = wmn / WN, wn = wmn % WN;
   const int li = lane & 31, lh = lane >> 5;
 
+  // loader constants: (row, channel) of each pass; channels beyond the tensor read channel 0 and are zeroed
+  int a_row[APASS], a_col[APASS], b_row[BPASS], b_col[BPASS];
+  bool a_cok[APASS], b_cok[BPASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    int idx = tid + i * NT;
+    a_row[i] = idx / (BMO / 4);
+    int co = co0 + (idx % (BMO / 4)) * 4;
+    a_cok[i] = (idx < F4A) && (co + 3 < p.Cout || co < p.Cout);   // Cout is padded to a multiple of 4 in dy
+    a_col[i] = a_cok[i] ? co : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    int idx = tid + i * NT;
+    b_row[i] = idx / (BNI / 4);
+    int ci = ci0 + (idx % (BNI / 4)) * 4;
+    b_cok[i] = (idx < F4B) && (ci < p.Cin);
+    b_col[i] = b_cok[i] ? ci : 0;
+  }
+
   f32x4 a_reg[APASS], b_reg[BPASS];
-  auto load_global = [&](int it) {
-    const int mb = m_begin + it * RA;
+  unsigned okmask = 0;   // bits [0,APASS): dy rows valid; bits [8,8+BPASS): x rows valid
+  int ld_m = m_begin;
+  auto load_global = [&](f32x4 (&ar)[APASS], f32x4 (&br)[BPASS], unsigned& okm) {
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      int idx = tid + i * NT;
-      int row = idx / (BMO / 4), c4 = (idx % (BMO / 4)) * 4;
-      int m = mb + row;
-      int co = co0 + c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < F4A && m < m_end && co < p.Cout) {
-        const float* src = p.dy + (int64_t)m * p.lddy + co;
-        if (co + 3 < p.Cout) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {  // ragged channel tail (the 20-channel head)
-          v[0] = src[0];
-          if (co + 1 < p.Cout) v[1] = src[1];
-          if (co + 2 < p.Cout) v[2] = src[2];
-        }
-      }
-      a_reg[i] = v;
+      int m = ld_m + a_row[i];
+      bool ok = a_cok[i] && (m < m_end);
+      int mc = ok ? m : m_begin;
+      ar[i] = *reinterpret_cast<const f32x4*>(p.dy + (int64_t)mc * p.lddy + a_col[i]);
+      okm |= ok ? (1u << i) : 0u;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      int idx = tid + i * NT;
-      int row = idx / (BNI / 4), c4 = (idx % (BNI / 4)) * 4;
-      int m = mb + row;
-      int ci = ci0 + c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < F4B && m < m_end && ci < p.Cin) {  // Cin is a multiple of 4
-        int xx = m % p.W + dx;
-        int yy = (m / p.W) % p.H + dy;
-        if (((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W))
-          v = *reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + xshift + ci);
-      }
-      b_reg[i] = v;
+      int m = ld_m + b_row[i];
+      int xx = m % p.W + dx;
+      int yy = (m / p.W) % p.H + dy;
+      bool ok = b_cok[i] && (m < m_end) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+      int64_t off = ok ? ((int64_t)m * p.ldx + xshift) : ((int64_t)m_begin * p.ldx);
+      br[i] = *reinterpret_cast<const f32x4*>(p.x + off + b_col[i]);
+      okm |= ok ? (1u << (8 + i)) : 0u;
     }
+    ld_m += RA;   // past m_end every row is masked off, so running ahead is harmless
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int slot, const f32x4 (&ar)[APASS], const f32x4 (&br)[BPASS], unsigned okm) {
+    float* As = smem + slot * SLOT;
+    float* Bs = As + RA * BMO;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       int idx = tid + i * NT;
-      if (idx < F4A) *reinterpret_cast<f32x4*>(As + buf * RA * BMO + idx * 4) = a_reg[i];
+      const bool ok = (okm >> i) & 1u;
+      f32x4 v;
+      v[0] = ok ? ar[i][0] : 0.f; v[1] = ok ? ar[i][1] : 0.f; v[2] = ok ? ar[i][2] : 0.f; v[3] = ok ? ar[i][3] : 0.f;
+      if (F4A % NT == 0 || idx < F4A) *reinterpret_cast<f32x4*>(As + idx * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       int idx = tid + i * NT;
-      if (idx < F4B) *reinterpret_cast<f32x4*>(Bs + buf * RA * BNI + idx * 4) = b_reg[i];
+      const bool ok = (okm >> (8 + i)) & 1u;
+      f32x4 v;
+      v[0] = ok ? br[i][0] : 0.f; v[1] = ok ? br[i][1] : 0.f; v[2] = ok ? br[i][2] : 0.f; v[3] = ok ? br[i][3] : 0.f;
+      if (F4B % NT == 0 || idx < F4B) *reinterpret_cast<f32x4*>(Bs + idx * 4) = v;
     }
   };
 
@@ -118,35 +136,54 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (niter > 0) {
-    load_global(0);
-    store_lds(0);
+  {
+    f32x4 a0[APASS], b0[BPASS], a1[APASS], b1[BPASS];
+    unsigned k0 = 0, k1 = 0;
+    load_global(a0, b0, k0);
+    load_global(a1, b1, k1);
+    load_global(a_reg, b_reg, okmask);
+    store_lds(0, a0, b0, k0);
+    store_lds(1, a1, b1, k1);
   }
   __syncthreads();
 
+  // MFMA operands of k-step kk: A[i=cout][k=pixel row 2kk+lh], B[k][j=cin]: conflict-free ds_read_b32 rows
+  auto read_frag = [&](int slot, int kk, float (&av)[TM], float (&bv)[TN]) {
+    const float* Ab = smem + slot * SLOT + (wk * 16 + lh + kk * 2) * BMO + wm * WTM + li;
+    const float* Bb = smem + slot * SLOT + RA * BMO + (wk * 16 + lh + kk * 2) * BNI + wn * WTN + li;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[i] = Ab[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = Bb[j * 32];
+  };
+  float av[2][TM], bv[2][TN];
+  read_frag(0, 0, av[0], bv[0]);
+
+  int slot = 0;
   for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < niter) load_global(it + 1);
-    const float* Ab = As + (buf * RA + wk * 16 + lh) * BMO + wm * WTM + li;
-    const float* Bb = Bs + (buf * RA + wk * 16 + lh) * BNI + wn * WTN + li;
+    const int slot1 = (slot == 2) ? 0 : slot + 1;
+    const int slot2 = (slot1 == 2) ? 0 : slot1 + 1;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ab[kk * 2 * BMO + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bb[kk * 2 * BNI + j * 32];
+      if (kk + 1 < 8) {
+        read_frag(slot, kk + 1, av[(kk + 1) & 1], bv[(kk + 1) & 1]);
+      } else {
+        read_frag(slot1, 0, av[0], bv[0]);
+      }
+      if (kk == 0) {
+        store_lds(slot2, a_reg, b_reg, okmask);
+        load_global(a_reg, b_reg, okmask);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
     }
-    if (it + 1 < niter) store_lds(buf ^ 1);
     __syncthreads();
+    slot = slot1;
   }
 
-  if (niter <= 0) return;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -159,6 +196,121 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
           atomicAdd(p.dw + ((int64_t)co * taps + tap) * p.Cin + ci, acc[i][j][r]);
       }
     }
+}
+
+// ---- first-layer special case: Cin = 4 (RGB + zero pad), Cout = 32, 3x3 ------------------------------------------------
+// The generic kernel would spend a 32-wide MFMA column tile on 4 input channels per tap (8x wasted issue slots and
+// 3.7 ms at batch 64).  Here the nine taps are folded into the column dimension: cols = (tap, ci) = 36 -> three
+// 16-wide tiles of v_mfma_f32_16x16x4_f32, rows = cout.  The layer is HBM-bound (dY alone is 1.4 GB at batch 64).
+// Each of the 4 waves reduces its own 16 of the 64 staged pixels; the 4 partial 32x48 tiles are summed through LDS
+// and one workgroup issues one atomic per filter element.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) conv_wgrad_c4_kernel(WgradArgs p) {
+  constexpr int RA = 64;        // pixels per staged chunk
+  constexpr int CO = 32;        // couts
+  constexpr int LSA = CO + 16;  // LDS row strides (floats): consecutive pixel rows land 16 banks apart
+  constexpr int NCOL = 48;      // 36 real (tap, ci) columns padded to 3 MFMA tiles
+  constexpr int LSB = NCOL;
+  __shared__ __attribute__((aligned(16))) float smem[2 * RA * (LSA + LSB)];
+  float* As = smem;                    // [2][RA][LSA]  dY
+  float* Bs = smem + 2 * RA * LSA;     // [2][RA][LSB]  X gathered over the 9 taps
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m_begin = blockIdx.x * p.chunk_m;
+  const int m_end = min(p.M, m_begin + p.chunk_m);
+  const int niter = (m_end - m_begin + RA - 1) / RA;
+  if (niter <= 0) return;
+
+  // zero the 12 padding columns once (both buffers); they are never written again
+  for (int i = tid; i < 2 * RA * 12; i += 256) Bs[(i / 12) * LSB + 36 + i % 12] = 0.f;
+
+  // loader roles: dY -> 2 float4 per thread; X -> pixel (tid & 63), taps {tid>>6, +4, +8}
+  const int a_row0 = tid >> 3, a_c4 = (tid & 7) * 4;       // rows a_row0 and a_row0 + 32
+  const int g_pix = tid & 63, g_tap0 = tid >> 6;
+  f32x4v a_reg[2], g_reg[3];
+  auto load_global = [&](int it) {
+    const int mb = m_begin + it * RA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = mb + a_row0 + i * 32;
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) v = *reinterpret_cast<const f32x4v*>(p.dy + (int64_t)m * p.lddy + a_c4);
+      a_reg[i] = v;
+    }
+    const int m = mb + g_pix;
+    const int x = m % p.W, y = (m / p.W) % p.H;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tap = g_tap0 + 4 * i;
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (tap < 9 && m < m_end) {
+        int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int yy = y + dy, xx = x + dx;
+        if (((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W))
+          v = *reinterpret_cast<const f32x4v*>(p.x + ((int64_t)m + dy * p.W + dx) * p.ldx);
+      }
+      g_reg[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<f32x4v*>(As + (buf * RA + a_row0 + i * 32) * LSA + a_c4) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tap = g_tap0 + 4 * i;
+      if (tap < 9) *reinterpret_cast<f32x4v*>(Bs + (buf * RA + g_pix) * LSB + tap * 4) = g_reg[i];
+    }
+  };
+
+  f32x4v acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  const int li = lane & 15, lk = lane >> 4;
+  for (int it = 0; it < niter; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < niter) load_global(it + 1);
+    // this wave's 16 pixels: 4 k-steps of 4 pixels; A[i=cout][k=pixel], B[k=pixel][j=col]
+    const float* Ab = As + (buf * RA + wid * 16 + lk) * LSA + li;
+    const float* Bb = Bs + (buf * RA + wid * 16 + lk) * LSB + li;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float av[2], bv[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = Ab[kk * 4 * LSA + i * 16];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bv[j] = Bb[kk * 4 * LSB + j * 16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < niter) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // sum the 4 waves' partial tiles through LDS: C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+  float* red = smem;   // [4][32][48]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wid * CO + i * 16 + lk * 4 + r) * NCOL + j * 16 + li] = acc[i][j][r];
+  __syncthreads();
+  for (int e = tid; e < CO * 36; e += 256) {
+    int co = e / 36, col = e % 36;
+    float v = red[(0 * CO + co) * NCOL + col] + red[(1 * CO + co) * NCOL + col] + red[(2 * CO + co) * NCOL + col] +
+              red[(3 * CO + co) * NCOL + col];
+    atomicAdd(p.dw + co * 36 + col, v);   // dw[co][tap][ci], Cin = 4
+  }
 }
 
 template <int BMO, int BNI, int WM, int WN, int WK>
@@ -178,7 +330,17 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
   a.nsplit = (int)nsplit;
   a.chunk_m = (int)chunk;
   dim3 grid((unsigned)(tiles * nsplit)), block(256);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMO, BNI, WM, WN, WK>), grid, block, 0, stream, a);
+  const int lds_bytes = 3 * RA * (BMO + BNI) * 4;
+  auto kern = conv_wgrad_kernel<BMO, BNI, WM, WN, WK>;
+  static int configured = 0;
+  if (lds_bytes > configured) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      ssp_set_error("conv_wgrad: cannot reserve %d bytes of LDS", lds_bytes);
+      return SSP_ERR_HIP;
+    }
+    configured = lds_bytes;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_wgrad");
   return SSP_OK;
 }
@@ -195,6 +357,16 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = B * H * W;
   SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)a.M * Cout * (double)(R * R * Cin));
+  if (Cin == 4 && Cout == 32 && R == 3 && ldx == 4 && ssp_option(SSP_OPT_WGRAD_VARIANT) != 1) {
+    // ~8 workgroups per CU, each a multiple of 64 pixels
+    int64_t chunk = (a.M + 2047) / 2048;
+    chunk = (chunk + 63) / 64 * 64;
+    a.chunk_m = (int)chunk;
+    a.nsplit = ssp_cdiv(a.M, chunk);
+    hipLaunchKernelGGL(conv_wgrad_c4_kernel, dim3(a.nsplit), dim3(256), 0, stream, a);
+    SSP_CHECK_LAUNCH("conv_wgrad_c4");
+    return SSP_OK;
+  }
   const int bo = Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
   const int bi = Cin >= 128 ? 128 : (Cin >= 64 ? 64 : 32);
   if (bo == 128 && bi == 128) return launch_wgrad<128, 128, 2, 2, 1>(a, stream);

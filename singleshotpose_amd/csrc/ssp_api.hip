@@ -8,7 +8,7 @@
 #include "ssp_common.h"
 
 // ---- kernels' host launchers (defined next to the kernels) ----
-int ssp_conv_tile_m(int Cout);
+int ssp_conv_tile_m(int M, int Cout);
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int prof_kind,
                           hipStream_t stream);
@@ -57,6 +57,11 @@ void ssp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- tuning knobs ----
+static int g_options[SSP_OPT_COUNT] = {1, 0, 0};
+static const char* g_option_names[SSP_OPT_COUNT] = {"igemm_xcd", "igemm_variant", "wgrad_variant"};
+int ssp_option(int which) { return g_options[which]; }
+
 // ---- launch timer ----
 namespace {
 struct ProfRec {
@@ -97,13 +102,22 @@ extern "C" {
 
 const char* ssp_last_error(void) { return g_err; }
 int ssp_abi_version(void) { return 1; }
+int ssp_set_option(const char* name, int value) {
+  for (int i = 0; i < SSP_OPT_COUNT; ++i)
+    if (name != nullptr && strcmp(name, g_option_names[i]) == 0) {
+      g_options[i] = value;
+      return SSP_OK;
+    }
+  ssp_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+  return SSP_ERR_ARG;
+}
 
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
                  int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream) {
   return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate,
                                SSP_PROF_CONV_FWD, (hipStream_t)stream);
 }
-int ssp_conv_stats_tile_m(int Cout) { return ssp_conv_tile_m(Cout); }
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cout) { return ssp_conv_tile_m(B * H * W, Cout); }
 
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
                    int lddx, int R, int accumulate, void* stream) {

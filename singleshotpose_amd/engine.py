@@ -131,7 +131,7 @@ class Plan(object):
                     cs.out = _Act(alloc(B * Ho * Wo * cs.coutp, **f32), 0, c, Ho, Wo, cs.coutp)
                 else:
                     cs.out = _Act(cs.raw, 0, c, cs.H, cs.W, cs.coutp)
-                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', c)
+                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, c)
                 cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
                 if cs.bn:
                     cs.stats = torch.empty(cs.ntile * c * 2, **f32)

@@ -50,7 +50,7 @@ def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
     wd = G.pack_fwd(w, cinp)
     out = torch.full((B * H * W, ldout), float('nan'), dtype=torch.float32, device=G.dev())
     bd = bvec.to(G.dev()) if bias else None
-    tile_m = _lib.query('ssp_conv_stats_tile_m', Cout)
+    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cout)
     ntile = (B * H * W + tile_m - 1) // tile_m
     stats = torch.zeros(ntile * Cout * 2, dtype=torch.float32, device=G.dev())
     _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,

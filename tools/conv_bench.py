@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--B', type=int, default=64)
     ap.add_argument('--opt', default='', help='name=value,... passed to ssp_set_option')
+    ap.add_argument('--variants', default='', help='comma list: run every case once per igemm_variant value')
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(',')):
         k, v = kv.split('=')
@@ -33,6 +34,15 @@ def main():
     dev = torch.device('cuda', 0)
     st = torch.cuda.current_stream().cuda_stream
     B = args.B
+    variants = [int(v) for v in args.variants.split(',')] if args.variants else [None]
+    for variant in variants:
+      if variant is not None:
+        _lib.call('ssp_set_option', b'igemm_variant', variant)
+        print('VARIANT', variant, flush=True)
+      run_cases(args, dev, st, B)
+
+
+def run_cases(args, dev, st, B):
     for name in args.cases.split(','):
         H, Cin, Cout, R = CASES[name]
         W = H
@@ -46,8 +56,7 @@ def main():
         out = torch.empty(M * coutp, device=dev)
         dx = torch.empty(M * Cin, device=dev)
         dw = torch.zeros(Cout * R * R * Cin, device=dev)
-        tile_m = _lib.query('ssp_conv_stats_tile_m', Cout)
-        stats = torch.empty(((M + tile_m - 1) // tile_m) * Cout * 2, device=dev)
+        stats = torch.empty(((M + 63) // 64) * Cout * 2, device=dev)  # sized for the smallest M tile any variant uses
         flop = 2.0 * M * Cout * R * R * Cin
         fns = {
             'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
