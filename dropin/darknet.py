@@ -1,0 +1,2 @@
+"""Drop-in for the reference's darknet.py (train.py / valid.py do `from darknet import Darknet`)."""
+from singleshotpose_amd.darknet import (Darknet, EmptyModule, GlobalAvgPool2d, MaxPoolStride1, Reorg)  # noqa: F401

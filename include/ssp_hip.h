@@ -95,6 +95,11 @@ int ssp_region_loss(const float* out, const void* target, int target_is_f64, flo
 int ssp_region_decode_argmax(const float* out, float* boxes, int nB, int nA, int nC, int nH, int nW,
                              int num_keypoints, int only_objectness, void* stream);
 
+/* get_multi_region_boxes (multi_obj_pose_estimation/utils_multi.py:266-382): dense decode, scan order
+ * key = (cy*nW + cx)*nA + anchor: rows[b][key][2K+3+nC] = {2K coords, det_conf, cls_max_conf, cls_max_id, softmax[nC]} */
+int ssp_region_decode_all(const float* out, float* rows, int nB, int nA, int nC, int nH, int nW, int num_keypoints,
+                          void* stream);
+
 /* ---- PnP (utils.py:86-100: cv2.solvePnP ITERATIVE + cv2.Rodrigues) ----------------------------------------- */
 /* batched: pts3d [n][N][3], pts2d [n][N][2], K [n][9] (row-major) doubles on the device -> Rt [n][12] = R (9) | t (3) */
 int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N, int max_iter,

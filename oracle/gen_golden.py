@@ -144,6 +144,23 @@ def main():
     np.savez_compressed(os.path.join(GOLD, 'decode.npz'), **rec)
     print('decode', rec['box_a'][-3:])
 
+    # ---- get_multi_region_boxes (multi-object validator decode), incl. the fallback-box path ----
+    sys.path.insert(0, mdir)
+    import utils_multi as ref_utils_multi
+    rs = np.random.RandomState(8)
+    o = rs.standard_normal((2, 160, 13, 13)).astype(np.float32)
+    o5 = o.reshape(2, 5, 32, 13, 13)
+    o5[:, :, 18] -= 4.0                       # few confident cells
+    o5[:, :, 19 + 7] -= 30.0                  # class 7 is never the arg-max -> fallback box for correspondingclass=7
+    rec = dict(output=o, anchors=np.array(anchors))
+    for corr in (4, 7):
+        with contextlib.redirect_stdout(io.StringIO()):
+            boxes = ref_utils_multi.get_multi_region_boxes(torch.from_numpy(o), 0.05, 13, 9, anchors, 5, corr, only_objectness=0)
+        for b, bl in enumerate(boxes):
+            rec['boxes_c%d_b%d' % (corr, b)] = np.array([[float(v) for v in bx] for bx in bl], dtype=np.float64).reshape(len(bl), -1)
+    np.savez_compressed(os.path.join(GOLD, 'decode_multi.npz'), **rec)
+    print('decode_multi', [rec['boxes_c%d_b%d' % (c, b)].shape for c in (4, 7) for b in (0, 1)])
+
     # ---- Reorg (bit-exact) ----
     rs = np.random.RandomState(4)
     x = rs.standard_normal((2, 8, 6, 10)).astype(np.float32)

@@ -182,3 +182,48 @@ def get_region_boxes_ref(output, num_classes, num_keypoints, only_objectness=1):
         box.append(float(xs[j][ind] / w))
         box.append(float(ys[j][ind] / h))
     return box + [float(det[ind]), float(cmax[ind]), int(cid[ind])]
+
+
+def get_multi_region_boxes_ref(output, conf_thresh, num_classes, num_keypoints, num_anchors, correspondingclass,
+                               only_objectness=1):
+    """utils_multi.py:266-382 restated (validation=False): per image, every (cy, cx, anchor) whose confidence exceeds
+    the threshold, plus a fallback box of `correspondingclass` when none of the kept boxes has that class.
+    max_cls_conf and max_ind persist across images (utils_multi.py:281,316-330)."""
+    K, nA, nC = num_keypoints, num_anchors, num_classes
+    if output.dim() == 3:
+        output = output.unsqueeze(0)
+    B, h, w = output.size(0), output.size(2), output.size(3)
+    o = output.float().view(B * nA, 2 * K + 1 + nC, h * w).transpose(0, 1).contiguous().view(2 * K + 1 + nC, B * nA * h * w)
+    gx = torch.linspace(0, w - 1, w).repeat(h, 1).repeat(B * nA, 1, 1).view(-1)
+    gy = torch.linspace(0, h - 1, h).repeat(w, 1).t().repeat(B * nA, 1, 1).view(-1)
+    xs = [torch.sigmoid(o[0]) + gx] + [o[2 * j] + gx for j in range(1, K)]
+    ys = [torch.sigmoid(o[1]) + gy] + [o[2 * j + 1] + gy for j in range(1, K)]
+    det = torch.sigmoid(o[2 * K])
+    cls_conf = torch.softmax(o[2 * K + 1:2 * K + 1 + nC].transpose(0, 1), dim=1)
+    cmax, cid = torch.max(cls_conf, 1)
+    sz_hw, sz_hwa = h * w, h * w * nA
+    max_cls_conf, max_ind = -float('inf'), None
+    all_boxes = []
+
+    def make(ind, det_conf, cls_max_conf, cls_max_id):
+        box = []
+        for j in range(K):
+            box.append(float(xs[j][ind] / w))
+            box.append(float(ys[j][ind] / h))
+        return box + [float(det_conf), float(cls_max_conf), int(cls_max_id)]
+
+    for b in range(B):
+        boxes, max_conf = [], -1
+        for cy in range(h):
+            for cx in range(w):
+                for i in range(nA):
+                    ind = b * sz_hwa + i * sz_hw + cy * w + cx
+                    conf = det[ind] if only_objectness else det[ind] * cmax[ind]
+                    if det[ind] > max_conf and cls_conf[ind, correspondingclass] > max_cls_conf:
+                        max_conf, max_cls_conf, max_ind = det[ind], cls_conf[ind, correspondingclass], ind
+                    if conf > conf_thresh:
+                        boxes.append(make(ind, det[ind], cmax[ind], cid[ind]))
+        if len(boxes) == 0 or correspondingclass not in [bx[2 * K + 2] for bx in boxes]:
+            boxes.append(make(max_ind, max_conf, max_cls_conf, correspondingclass))
+        all_boxes.append(boxes)
+    return all_boxes

@@ -47,6 +47,7 @@ _SIGS = {
     "ssp_maxpool_bwd": [P, I, P, I, P, I, I, I, I, I, I, P],
     "ssp_region_loss": [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, F, I, I, P, I, P],
     "ssp_region_decode_argmax": [P, P, I, I, I, I, I, I, I, P],
+    "ssp_region_decode_all": [P, P, I, I, I, I, I, I, P],
     "ssp_pnp_batched": [P, P, P, P, I, I, I, P],
     "ssp_prof_enable": [I],
     "ssp_prof_nkinds": [],

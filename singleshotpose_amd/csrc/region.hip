@@ -312,6 +312,56 @@ __global__ void __launch_bounds__(256) region_decode_argmax_kernel(const float* 
   }
 }
 
+// Dense decode for get_multi_region_boxes (utils_multi.py:266-382): every (cell, anchor) in the reference's scan order
+// key = (cy*nW + cx)*nA + anchor -> rows[b][key] = {2K coords / (w,h), det_conf, cls_max_conf, cls_max_id, softmax[nC]}.
+// The variable-length box lists (threshold, fallback box) are assembled on the host from this one tensor.
+template <int K>
+__global__ void __launch_bounds__(256) region_decode_all_kernel(const float* __restrict__ out, int nA, int nC, int nH,
+                                                                int nW, float* rows) {
+  const int b = blockIdx.y;
+  const int nCh = 2 * K + 1 + nC;
+  const int W = 2 * K + 3 + nC;
+  const int64_t hw = (int64_t)nH * nW;
+  const int ncell = nA * nH * nW;
+  for (int key = blockIdx.x * blockDim.x + threadIdx.x; key < ncell; key += gridDim.x * blockDim.x) {
+    int an = key % nA, rem = key / nA;
+    int j = rem / nW, i = rem % nW;
+    int64_t base = ((int64_t)(b * nA + an) * nCh) * hw + rem;
+    float* o = rows + ((int64_t)b * ncell + key) * W;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float vx = out[base + (2 * k) * hw], vy = out[base + (2 * k + 1) * hw];
+      if (k == 0) { vx = sigmoidf_(vx); vy = sigmoidf_(vy); }
+      o[2 * k] = (vx + (float)i) / (float)nW;
+      o[2 * k + 1] = (vy + (float)j) / (float)nH;
+    }
+    o[2 * K] = sigmoidf_(out[base + (2 * K) * hw]);
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int q = 0; q < nC; ++q) {
+      float z = out[base + (2 * K + 1 + q) * hw];
+      if (z > mx) { mx = z; arg = q; }
+    }
+    float se = 0.f;
+    for (int q = 0; q < nC; ++q) se += expf(out[base + (2 * K + 1 + q) * hw] - mx);
+    for (int q = 0; q < nC; ++q) o[2 * K + 3 + q] = expf(out[base + (2 * K + 1 + q) * hw] - mx) / se;
+    o[2 * K + 1] = 1.f / se;
+    o[2 * K + 2] = (float)arg;
+  }
+}
+
+int ssp_region_decode_all_launch(const float* out, float* rows, int nB, int nA, int nC, int nH, int nW,
+                                 int num_keypoints, hipStream_t stream) {
+  SSP_CHECK_ARG(num_keypoints == 9, "region_decode_all: only num_keypoints == 9 is built (got %d)", num_keypoints);
+  SSP_CHECK_ARG(nC >= 1 && nA >= 1, "region_decode_all: need at least one class and one anchor");
+  SspProfScope prof(SSP_PROF_REGION, stream, 0.0);
+  const int ncell = nA * nH * nW;
+  hipLaunchKernelGGL((region_decode_all_kernel<9>), dim3(ssp_cdiv(ncell, 256), nB), dim3(256), 0, stream, out, nA, nC,
+                     nH, nW, rows);
+  SSP_CHECK_LAUNCH("region_decode_all");
+  return SSP_OK;
+}
+
 int ssp_region_loss_launch(const float* out, const void* target, int target_is_f64, float* grad, float* partials,
                            float* stats, int nB, int nA, int nC, int nH, int nW, int num_keypoints,
                            float noobject_scale, float object_scale, float coord_scale, float class_scale, float thresh,

@@ -45,6 +45,8 @@ int ssp_region_loss_launch(const float* out, const void* target, int target_is_f
                            int conf_on, int multi, const float* anchors, int anchor_step, hipStream_t stream);
 int ssp_region_decode_argmax_launch(const float* out, float* boxes, int nB, int nA, int nC, int nH, int nW,
                                     int num_keypoints, int only_objectness, hipStream_t stream);
+int ssp_region_decode_all_launch(const float* out, float* rows, int nB, int nA, int nC, int nH, int nW,
+                                 int num_keypoints, hipStream_t stream);
 int ssp_pnp_batched_launch(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N,
                            int max_iter, hipStream_t stream);
 
@@ -200,6 +202,11 @@ int ssp_region_decode_argmax(const float* out, float* boxes, int nB, int nA, int
                              int num_keypoints, int only_objectness, void* stream) {
   return ssp_region_decode_argmax_launch(out, boxes, nB, nA, nC, nH, nW, num_keypoints, only_objectness,
                                          (hipStream_t)stream);
+}
+
+int ssp_region_decode_all(const float* out, float* rows, int nB, int nA, int nC, int nH, int nW, int num_keypoints,
+                          void* stream) {
+  return ssp_region_decode_all_launch(out, rows, nB, nA, nC, nH, nW, num_keypoints, (hipStream_t)stream);
 }
 
 int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N, int max_iter,

@@ -1,0 +1,73 @@
+"""Data-parallel gradient exchange on CPU: 2 processes, gloo, 127.0.0.1 (the N>1 path of bench.py minus the GPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from singleshotpose_amd.dist import GradReducer, init_distributed
+    import torch.distributed as dist
+    init_distributed('gloo')
+    assert dist.get_world_size() == world
+    # layer gradients arrive in flat-buffer order (reverse layer order), sizes like a small conv net
+    sizes = [4000, 12, 900, 30000, 64, 64, 70000, 5]
+    offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
+    total = int(offs[-1])
+    red = GradReducer(None, world, bucket_bytes=40000 * 4)
+    results = []
+    for step in range(2):                                   # a fresh flat buffer every backward
+        g = torch.Generator().manual_seed(100 * step + rank)
+        flat = torch.randn(total, generator=g)
+        local = flat.clone()
+        for i in range(len(sizes)):
+            red.layer_done(flat, int(offs[i]), int(offs[i + 1]))
+        red.all_reduce()
+        results.append((local, flat.clone(), list(red.launched)))
+    q.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_sum_two_ranks():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(2):
+        expected = out[0][step][0] + out[1][step][0]        # SUM, not mean (reference loss is a batch sum)
+        for r in range(world):
+            assert torch.allclose(out[r][step][1], expected, rtol=0, atol=1e-6)
+        buckets = out[0][step][2]
+        assert buckets == out[1][step][2]
+        # contiguous, ordered, covering the whole buffer; every bucket but the last reaches the size threshold
+        assert buckets[0][0] == 0 and buckets[-1][1] == expected.numel()
+        assert all(b[1] == c[0] for b, c in zip(buckets, buckets[1:]))
+        assert all(b[1] - b[0] >= 40000 for b in buckets[:-1]) and len(buckets) >= 2
+
+
+def test_reducer_is_inert_for_one_rank():
+    from singleshotpose_amd.dist import GradReducer
+    red = GradReducer(None, 1)
+    flat = torch.ones(16)
+    red.layer_done(flat, 0, 16)
+    red.all_reduce()
+    assert torch.equal(flat, torch.ones(16)) and not red.active

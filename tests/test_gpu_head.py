@@ -115,6 +115,21 @@ def test_get_region_boxes_golden():
     assert abs(float(per[1, 0]) - (0.5 + 3) / 5) < 1e-6
 
 
+def test_get_multi_region_boxes_golden():
+    from singleshotpose_amd.utils_multi import bbox_iou, get_multi_region_boxes
+    g = gold('decode_multi.npz')
+    anchors = [float(a) for a in g['anchors']]
+    out = torch.from_numpy(g['output']).cuda()
+    for corr in (4, 7):
+        boxes = get_multi_region_boxes(out, 0.05, 13, 9, anchors, 5, corr, only_objectness=0)
+        assert len(boxes) == 2
+        for b, bl in enumerate(boxes):
+            ref = g['boxes_c%d_b%d' % (corr, b)]
+            assert len(bl) == ref.shape[0]
+            np.testing.assert_allclose(np.array(bl, dtype=np.float64), ref, rtol=1e-4, atol=1e-6)
+    assert abs(bbox_iou([0, 0, 2, 2], [0, 0, 1, 3]) - 0.4) < 1e-12
+
+
 def test_pnp_round_trip_and_oracle():
     from oracle.pnp_ref import project, rodrigues, solve_pnp_ref
     from singleshotpose_amd.utils import pnp, pnp_batched

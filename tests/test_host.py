@@ -1,0 +1,184 @@
+"""CPU-only checks: C-ABI surface, cfg / weights formats, host-side mirror of the reference interface, helpers."""
+import io
+import os
+import re
+import contextlib
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLD, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from singleshotpose_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ssp_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(ssp_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)          # dlopen only: no GPU call is made on the CPU box
+    for name in declared:
+        assert hasattr(lib, name), "libssp_hip.so does not export %s" % name
+    # the ctypes table covers the whole header and nothing else
+    assert sorted(_lib.exported_symbols()) == declared
+    assert _lib.query('ssp_abi_version') == 1
+    with pytest.raises(_lib.SspError, match="unknown option"):
+        _lib.call('ssp_set_option', b'no_such_knob', 1)
+
+
+def test_parse_cfg_and_shapes():
+    from singleshotpose_amd.cfg import layer_shapes, parse_cfg, print_cfg
+    blocks = parse_cfg(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    assert len(blocks) == 33 and blocks[0]['type'] == 'net' and blocks[-1]['type'] == 'region'
+    assert blocks[0]['steps'] == '-1,80,160' and blocks[0]['test_width'] == '672'    # values stay strings
+    assert blocks[1]['batch_normalize'] == '1' and blocks[31]['batch_normalize'] == 0  # default for the head conv
+    assert blocks[-1]['anchors'] == '' and blocks[-1]['classes'] == '1'
+    shapes = layer_shapes(blocks)
+    assert shapes[0] == (416, 416, 32) and shapes[16] == (26, 26, 512)
+    assert shapes[27] == (13, 13, 256) and shapes[28] == (13, 13, 1280) and shapes[30] == (13, 13, 20)
+    assert layer_shapes(blocks, 672, 672)[30] == (21, 21, 20)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        print_cfg(blocks)
+    lines = buf.getvalue().splitlines()
+    assert lines[1] == '    0 conv     32  3 x 3 / 1   416 x 416 x   3   ->   416 x 416 x  32'
+    assert lines[2] == '    1 max          2 x 2 / 2   416 x 416 x  32   ->   208 x 208 x  32'
+    assert lines[26] == '   25 route  16'
+    assert lines[28] == '   27 reorg              / 2    26 x  26 x  64   ->    13 x  13 x 256'
+    assert lines[29] == '   28 route  27 24'
+    assert lines[31] == '   30 conv     20  1 x 1 / 1    13 x  13 x1024   ->    13 x  13 x  20'
+    assert lines[32] == '   31 detection'
+    multi = parse_cfg(os.path.join(ROOT, 'cfg', 'yolo-pose-multi.cfg'))
+    assert multi[31]['filters'] == '160' and multi[-1]['num'] == '5' and multi[-1]['classes'] == '13'
+    assert len(multi[-1]['anchors'].split(',')) == 10
+
+
+def test_module_tree_and_weight_round_trip(tmp_path):
+    from oracle.darknet_ref import seeded_state, write_weights
+    from singleshotpose_amd.darknet import Darknet
+    cfg = os.path.join(GOLD, 'tiny-pose.cfg')
+    m = Darknet(cfg)
+    names = [n for n, _ in m.named_parameters()]
+    assert names[:3] == ['models.0.conv1.weight', 'models.0.bn1.weight', 'models.0.bn1.bias']
+    assert names[-2:] == ['models.19.conv12.weight', 'models.19.conv12.bias']
+    assert all(('.bn' in n) or ('.bias' in n) or ('.conv' in n) for n in names)     # train.py:384 filters on these
+    assert m.models[0][0].weight.shape == (8, 3, 3, 3) and m.models[0][1].eps == 1e-4
+    assert (m.width, m.height, m.test_width, m.num_keypoints, m.num_anchors, m.num_classes) == (96, 96, 160, 9, 1, 1)
+    assert m.anchors == [] and m.loss.noobject_scale == 0.1 and m.loss.object_scale == 5.0   # cfg-configured region loss
+
+    state = seeded_state(m.blocks, 31)
+    ref_file = str(tmp_path / 'ref.weights')
+    write_weights(ref_file, m.blocks, state, seen=77)        # oracle writer = the reference's stream order
+    m.load_weights(ref_file)
+    assert int(m.seen) == 77
+    assert torch.equal(m.models[4][0].weight, state[4]['weight'])
+    assert torch.equal(m.models[4][1].running_var, state[4]['running_var'])
+    assert torch.equal(m.models[19][0].bias, state[19]['bias'])
+    out_file = str(tmp_path / 'out.weights')
+    m.save_weights(out_file)
+    assert open(out_file, 'rb').read() == open(ref_file, 'rb').read()    # byte-exact round trip
+
+    # load_weights_until_last leaves the head conv (and everything after it) untouched (darknet.py:310)
+    m2 = Darknet(cfg)
+    head_before = m2.models[19][0].weight.clone()
+    m2.load_weights_until_last(ref_file)
+    assert torch.equal(m2.models[18][0].weight, state[18]['weight'])
+    assert torch.equal(m2.models[19][0].weight, head_before)
+    # cutoff: only the first blocks are written
+    m.save_weights(str(tmp_path / 'cut.weights'), cutoff=3)
+    assert os.path.getsize(str(tmp_path / 'cut.weights')) == 16 + 4 * (4 * 8 + 8 * 27 + 4 * 16 + 16 * 8 * 9)
+
+
+def test_no_cpu_fallback():
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    from singleshotpose_amd.utils import get_region_boxes
+    m = Darknet(os.path.join(GOLD, 'tiny-pose.cfg'))
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(torch.zeros(1, 3, 96, 96))
+    with pytest.raises(RuntimeError, match="HIP"):
+        RegionLoss()(torch.zeros(1, 20, 3, 3), torch.zeros(1, 50 * 21), 0)
+    with pytest.raises(RuntimeError, match="HIP"):
+        get_region_boxes(torch.zeros(1, 20, 3, 3), 1, 9)
+    with pytest.raises(RuntimeError):
+        m.models[16](torch.zeros(1, 8, 6, 6))        # Reorg has no standalone eager path either
+    # nothing in the product package imports the oracle
+    pkg = os.path.join(ROOT, 'singleshotpose_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            assert 'oracle' not in open(os.path.join(pkg, fn)).read().replace('the oracle', '').replace('oracle/', ''), fn
+
+
+def test_unsupported_blocks_fail_loudly(tmp_path):
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.engine import Plan
+    cfg = tmp_path / 'bad.cfg'
+    cfg.write_text('[net]\nheight=32\nwidth=32\nchannels=3\n\n[convolutional]\nfilters=8\nsize=3\nstride=2\npad=1\nactivation=leaky\n')
+    m = Darknet(str(cfg))
+    with pytest.raises(NotImplementedError):
+        Plan(m, 1, 32, 32, torch.device('cpu'))
+
+
+def test_utils_helpers(tmp_path):
+    from singleshotpose_amd import utils as U
+    rs = np.random.RandomState(0)
+    verts = np.concatenate([rs.uniform(-0.05, 0.05, (3, 200)), np.ones((1, 200))], 0)
+    c = U.get_3D_corners(verts)
+    assert c.shape == (4, 8)
+    mn, mx = verts[:3].min(1), verts[:3].max(1)
+    np.testing.assert_allclose(c[:3, 0], mn)
+    np.testing.assert_allclose(c[:3, 1], [mn[0], mn[1], mx[2]])
+    np.testing.assert_allclose(c[:3, 4], [mx[0], mn[1], mn[2]])
+    np.testing.assert_allclose(c[:3, 7], mx)
+    K = U.get_camera_intrinsic(325.2611, 242.0489, 572.4114, 573.5704)
+    Rt = np.concatenate([np.eye(3), np.array([[0.01], [0.02], [0.9]])], 1)
+    proj = U.compute_projection(verts, Rt, K)
+    assert proj.shape == (2, 200) and proj.dtype == np.float32
+    p = K.dot(Rt.dot(verts))
+    np.testing.assert_allclose(proj, (p[:2] / p[2]).astype(np.float32), rtol=1e-6)
+    pts = verts[:3].T
+    brute = max(np.linalg.norm(pts[i] - pts[j]) for i in range(len(pts)) for j in range(i, len(pts)))
+    assert abs(U.calc_pts_diameter(pts) - brute) < 1e-9
+    assert abs(U.calcAngularDistance(np.eye(3), np.eye(3))) < 1e-6
+    d = tmp_path / 'x.data'
+    d.write_text('train  = a/train.txt\nvalid = a/test.txt\n\nfx = 572.4114 \n')
+    o = U.read_data_cfg(str(d))
+    assert o['gpus'] == '0' and o['num_workers'] == '10' and o['train'] == 'a/train.txt' and o['fx'] == '572.4114'
+    lab = tmp_path / 'l.txt'
+    lab.write_text(' '.join(str(i / 100.0) for i in range(21)) + '\n' + ' '.join(str(i / 50.0) for i in range(21)) + '\n')
+    t = U.read_truths_args(str(lab))
+    assert t.shape == (38,) and abs(t[19] - 0.0) < 1e-12 and abs(t[18] - 0.18) < 1e-12   # 19 numbers per row, packed
+    g = np.arange(18, dtype=np.float32).reshape(9, 2)
+    f = U.fix_corner_order(g)
+    assert f[2, 0] == g[3, 0] and f[5, 0] == g[2, 0] and f[8, 0] == g[8, 0]
+    pr = torch.rand(18, 7)
+    gt = torch.rand(18, 1).repeat(1, 7)
+    from oracle.region_loss_ref import corner_confidence_ref, corner_confidences_ref
+    np.testing.assert_allclose(U.corner_confidences(gt, pr).numpy(), corner_confidences_ref(gt, pr).numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(U.corner_confidence(list(gt[:, 0]), pr[:, 0])), float(corner_confidence_ref(gt[:, 0], pr[:, 0])), rtol=1e-5, atol=1e-7)
+
+
+def test_pnp_oracle_round_trip():
+    """The PnP restatement (oracle/pnp_ref.py, parity unpinned - no cv2 here) recovers synthetic poses."""
+    from oracle.pnp_ref import project, rodrigues, solve_pnp_ref
+    K = np.array([[572.4114, 0, 325.2611], [0, 573.5704, 242.0489], [0, 0, 1.0]])
+    X = np.concatenate([np.zeros((1, 3)), np.array([[sx * .038, sy * .039, sz * .046] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])], 0)
+    rs = np.random.RandomState(1)
+    for _ in range(20):
+        axis = rs.standard_normal(3)
+        R = rodrigues(axis / np.linalg.norm(axis) * rs.uniform(0, np.pi / 3))
+        t = np.array([rs.uniform(-.1, .1), rs.uniform(-.1, .1), rs.uniform(.6, 1.2)])
+        uv = project(X, R, t, K)
+        R2, t2 = solve_pnp_ref(X, uv, K)
+        assert np.abs(project(X, R2, t2, K) - uv).max() < 1e-6
+        assert np.abs(R2 - R).max() < 1e-6 and np.abs(t2.ravel() - t).max() < 1e-6
+        # 1 px noise: the LM result is a stationary point of the reprojection error
+        uvn = uv + rs.uniform(-1, 1, uv.shape)
+        R3, t3 = solve_pnp_ref(X, uvn, K)
+        e0 = ((project(X, R3, t3, K) - uvn) ** 2).sum()
+        for d in range(3):
+            for s in (-1e-4, 1e-4):
+                tt = t3.ravel().copy()
+                tt[d] += s
+                assert ((project(X, R3, tt, K) - uvn) ** 2).sum() >= e0 - 1e-9

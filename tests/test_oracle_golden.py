@@ -5,7 +5,7 @@ import torch
 
 from helpers import GOLD, clone_state, gold, golden_input, rel_err
 from oracle.darknet_ref import forward_ref, reorg_ref, seeded_state
-from oracle.region_loss_ref import get_region_boxes_ref, region_loss_ref
+from oracle.region_loss_ref import get_multi_region_boxes_ref, get_region_boxes_ref, region_loss_ref
 from singleshotpose_amd.cfg import parse_cfg
 
 import os
@@ -56,6 +56,18 @@ def test_decode_matches_reference():
     for name in ('a', 'b'):
         box = get_region_boxes_ref(torch.from_numpy(g['out_' + name]), 1, 9)
         np.testing.assert_allclose(np.array(box, dtype=np.float64), g['box_' + name], rtol=1e-6, atol=1e-7)
+
+
+def test_decode_multi_matches_reference():
+    g = gold('decode_multi.npz')
+    out = torch.from_numpy(g['output'])
+    for corr in (4, 7):
+        boxes = get_multi_region_boxes_ref(out, 0.05, 13, 9, 5, corr, only_objectness=0)
+        for b, bl in enumerate(boxes):
+            ref = g['boxes_c%d_b%d' % (corr, b)]
+            assert len(bl) == ref.shape[0]
+            np.testing.assert_allclose(np.array(bl, dtype=np.float64), ref, rtol=1e-5, atol=1e-6)
+    assert g['boxes_c7_b0'][-1, 20] == 7      # the fallback path is exercised
 
 
 def test_reorg_bit_exact():
