@@ -29,16 +29,21 @@ int ssp_set_option(const char* name, int value);
 /* ---- convolution (stride 1, "same" padding, R = 1 or 3): nn.Conv2d at darknet.py:156,160 ------------------- */
 
 /* out[p][co] (+)= sum_{tap,ci} in[p + tap][ci] * wt[co][tap][ci]  (+ bias[co]);  wt from ssp_repack_fwd.
- * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(B,H,W,Cout))][Cout][2] per-tile (mean, M2) of the raw output,
- * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157). */
+ * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(...))][Cout][2] per-tile (mean, M2) of the raw output,
+ * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157).
+ * workspace: ssp_conv_workspace_floats(...) floats (0 for most shapes; the 13x13 layers split their K loop over
+ * several workgroups per tile and sum the partial tiles from it).  The shape arguments of the two queries are those
+ * of the launch (for ssp_conv_dgrad: Cin = channels of dy, Cout = channels of dx). */
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
-                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream);
-int ssp_conv_stats_tile_m(int B, int H, int W, int Cout);
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* workspace,
+                 int64_t workspace_floats, void* stream);
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R);
+int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R);
 
 /* data gradient (autograd of nn.Conv2d, train.py:103): dx[p][ci] (+)= sum dy[p - tap][co] * w[co][ci][tap];
  * same contraction as ssp_conv_fwd with `wt` from ssp_repack_dgrad; Cout_dy = channels of dy (multiple of 4). */
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
-                   int lddx, int R, int accumulate, void* stream);
+                   int lddx, int R, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
 
 /* filter gradient: dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]; dw is [Cout][R*R][Cin] packed and must be
  * zeroed by the caller (split reduction uses fp32 atomics). */

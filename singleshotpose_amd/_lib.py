@@ -26,9 +26,10 @@ L = c_int64
 _SIGS = {
     "ssp_abi_version": [],
     "ssp_set_option": [c_char_p, I],
-    "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "ssp_conv_stats_tile_m": [I, I, I, I],
-    "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_stats_tile_m": [I, I, I, I, I, I],
+    "ssp_conv_workspace_floats": [I, I, I, I, I, I],
+    "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
     "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],
     "ssp_bn_eval_prepare": [I, P, P, P, P, F, P, P, P, P, P],
@@ -54,6 +55,8 @@ _SIGS = {
     "ssp_prof_collect": [P, P, P],
 }
 
+_RET64 = ('ssp_conv_workspace_floats',)
+
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region")
 
 
@@ -76,7 +79,7 @@ def load():
     lib.ssp_last_error.argtypes = []
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
-        fn.restype = c_int
+        fn.restype = c_int64 if name in _RET64 else c_int
         fn.argtypes = args
     _lib = lib
     return lib

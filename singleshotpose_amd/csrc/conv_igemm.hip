@@ -18,32 +18,7 @@
 // (cdna_hip_programming.md section 3).  The k order inside a BK chunk is arbitrary as long as A and B
 // agree, so lane (i,h) reads VEC consecutive floats at column h*VEC of its LDS row with one
 // ds_read_b128/b64 and feeds them to VEC successive MFMAs.
-#include <type_traits>
-
-#include "ssp_common.h"
-
-struct ConvArgs {
-  const float* in;
-  const float* wt;
-  float* out;
-  const float* bias;  // [Cout] or nullptr (added in the epilogue; the linear head conv)
-  float* stats;       // [ntile_m][Cout][2] = per-M-tile (mean, M2) of the raw output, or nullptr
-  int H, W, Cin, Cout, ldin, ldout, R, M;
-  int accumulate;     // out += result (second consumer of a routed activation in dgrad)
-  int ntile_m, ntile_n;
-  int xcd_remap;
-};
-
-__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-  float nt = n + nb;
-  if (nt > 0.f) {
-    float d = mb - mean;
-    float f = nb / nt;
-    mean += d * f;
-    m2 += m2b + d * d * n * f;
-    n = nt;
-  }
-}
+#include "conv_igemm_common.h"
 
 // ABL: 0 = product kernel; ablation bits for tools/conv_bench.py only (results are garbage): 1 no global loads in
 // the K loop, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no LDS stores
@@ -73,8 +48,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 * SLOT floats
 
-  const int nwg = p.ntile_m * p.ntile_n;
-  const int lid = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+  const int ntiles = p.ntile_m * p.ntile_n;
+  const int nwg = ntiles * p.ksplit;
+  const int lid0 = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+  const int split = lid0 / ntiles, lid = lid0 - split * ntiles;
   const int tile_n = lid % p.ntile_n, tile_m = lid / p.ntile_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -84,7 +61,8 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   const int pad = p.R >> 1;
   const int K = p.R * p.R * p.Cin;
   const int cpt = p.Cin / BK;  // K chunks per filter tap
-  const int niter = p.R * p.R * cpt;
+  const int it_begin = split * p.it_per_split;
+  const int niter = min(p.R * p.R * cpt, it_begin + p.it_per_split) - it_begin;   // this workgroup's K chunks
 
   // ---- loader setup: rows are fixed for the whole K loop ----
   const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
@@ -113,8 +91,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
   unsigned a_okmask = 0;   // bit i: pass i of the staged chunk is inside the image (applied at LDS-store time, so
                            // the zeroing select does not pull the s_waitcnt for the loads in front of the MFMAs)
   // K-chunk walker for the loader (chunks are visited in order; no per-chunk integer division)
-  int ld_c0 = 0, ld_dy = -pad, ld_dx = -pad;
-  int64_t ld_koff = 0;   // it * BK
+  const int tap0 = it_begin / cpt;
+  int ld_c0 = (it_begin - tap0 * cpt) * BK, ld_dy = tap0 / p.R - pad, ld_dx = tap0 % p.R - pad;
+  int64_t ld_koff = (int64_t)it_begin * BK;   // it * BK
   auto load_global = [&](f32x4 (&a_reg)[APASS], f32x4 (&b_reg)[BPASS], unsigned& a_okmask) {
     const int64_t shift = ((int64_t)ld_dy * p.W + ld_dx) * p.ldin + ld_c0;
 #pragma unroll
@@ -245,6 +224,35 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
       }
       mma(fa[q & 1], fb[q & 1]);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((ABL & 64) != 0) {     // overlap probe: 64 independent VALU ops per chunk
+      float t0 = 1.f, t1 = 2.f, t2 = 3.f, t3 = 4.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3"
+                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      asm volatile("" ::"v"(t0), "v"(t1), "v"(t2), "v"(t3));
+    }
+    if constexpr ((ABL & 128) != 0) {    // overlap probe: 64 SALU ops per chunk
+      int u0 = 1, u1 = 2;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 3" : "+s"(u0), "+s"(u1) : : "scc");
+      asm volatile("" ::"s"(u0), "s"(u1));
+    }
+    if constexpr ((ABL & 256) != 0) {    // overlap probe: 8 x ds_read_b128 + wait per chunk, results unused
+      f32x4 d0, d1, d2, d3, d4, d5, d6, d7;
+      const float* base = smem + (wm * WTM + li) * LS + lh * VEC;
+      d0 = *reinterpret_cast<const volatile f32x4*>(base);
+      d1 = *reinterpret_cast<const volatile f32x4*>(base + 8);
+      d2 = *reinterpret_cast<const volatile f32x4*>(base + 32 * LS);
+      d3 = *reinterpret_cast<const volatile f32x4*>(base + 32 * LS + 8);
+      d4 = *reinterpret_cast<const volatile f32x4*>(base + BM * LS);
+      d5 = *reinterpret_cast<const volatile f32x4*>(base + BM * LS + 8);
+      d6 = *reinterpret_cast<const volatile f32x4*>(base + (BM + 32) * LS);
+      d7 = *reinterpret_cast<const volatile f32x4*>(base + (BM + 32) * LS + 8);
+      asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));
+    }
+#endif
     if constexpr ((ABL & 4) == 0) __syncthreads();
     if constexpr ((NQ & 1) != 0) {   // odd NQ: the prefetched q=0 fragments sit in set 1, move them to set 0
 #pragma unroll
@@ -259,62 +267,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
     slot = slot1;
   }
 
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-  auto epilogue = [&](auto accum_tag) {
-  constexpr bool ACCUM = decltype(accum_tag)::value;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + li;
-    const bool n_ok = n < p.Cout;
-    const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
-    float cnt = 0.f, sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        int m = m0 + row;
-        float v = acc[i][j][r] + bias;
-        if (m < p.M && n_ok) {
-          float* o = p.out + (int64_t)m * p.ldout + n;
-          if constexpr (ACCUM) v += *o;
-          *o = v;
-          cnt += 1.f;
-          sum += acc[i][j][r];
-        }
-      }
-    }
-    if (p.stats != nullptr) {
-      // per-lane (count, mean, M2) of this lane's column over its valid rows, then Chan-combine:
-      // lane halves (rows +4) -> waves along M (through LDS) -> one (mean, M2) pair per column per M tile.
-      float mean = cnt > 0.f ? sum / cnt : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m0 + row < p.M && n_ok) {
-            float d = acc[i][j][r] - mean;
-            m2 += d * d;
-          }
-        }
-      }
-      float ocnt = __shfl_xor(cnt, 32), omean = __shfl_xor(mean, 32), om2 = __shfl_xor(m2, 32);
-      chan_combine(cnt, mean, m2, ocnt, omean, om2);
-      // smem is free again: the K loop ended with a barrier
-      float* red = smem;  // [WM][BN][3]
-      int col = wn * WTN + j * 32 + li;
-      if (lh == 0) {
-        red[(wm * BN + col) * 3 + 0] = cnt;
-        red[(wm * BN + col) * 3 + 1] = mean;
-        red[(wm * BN + col) * 3 + 2] = m2;
-      }
-    }
-  }
-  };
+  // ---- epilogue (conv_igemm_common.h) ----
   if constexpr ((ABL & 32) == 0) {
-    if (p.accumulate) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid);
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -325,20 +280,65 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
 #endif
       }
   }
-  if (p.stats != nullptr) {
-    __syncthreads();
-    for (int col = tid; col < BN; col += NT) {
-      int n = n0 + col;
-      if (n < p.Cout) {
-        float cnt = smem[col * 3 + 0], mean = smem[col * 3 + 1], m2 = smem[col * 3 + 2];
+}
+
+// Sum of the split-K partial tiles: out[m][n] (+)= sum_s ws[s][m][n] + bias[n], and - for BN layers - the per-row-tile
+// (mean, M2) statistics in the same format the conv epilogue emits (tile_m rows per tile).  HBM-bound: reads
+// ksplit*M*Cout floats once, writes M*Cout.  One workgroup per row tile; thread = 4 channels x a row lane.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
+                                                            const float* __restrict__ bias, float* stats, int M,
+                                                            int Cout, int tile_m, int accumulate) {
+  const int G = (Cout + 3) >> 2;
+  const int gpb = G < 256 ? G : 256, ppb = 256 / gpb;
+  const int tid = threadIdx.x, gl = tid % gpb, pp = tid / gpb;
+  const int m0 = blockIdx.x * tile_m, m1 = min(M, m0 + tile_m);
+  __shared__ float red[256][4][3];
+  for (int g0 = 0; g0 < G; g0 += gpb) {
+    const int g = g0 + gl;
+    const int c = g * 4;
+    const bool active = (pp < ppb) && (g < G);
+    float cnt = 0.f, mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      for (int m = m0 + pp; m < m1; m += ppb) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < ksplit; ++sp) {
+          const float* src = ws + ((int64_t)sp * M + m) * Cout + c;
 #pragma unroll
-        for (int w = 1; w < WM; ++w)
-          chan_combine(cnt, mean, m2, smem[(w * BN + col) * 3 + 0], smem[(w * BN + col) * 3 + 1],
-                       smem[(w * BN + col) * 3 + 2]);
-        float* s = p.stats + ((int64_t)tile_m * p.Cout + n) * 2;
-        s[0] = mean;
-        s[1] = m2;
+          for (int k = 0; k < 4; ++k)
+            if (c + k < Cout) v[k] += src[k];
+        }
+        cnt += 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float d = v[k] - mean[k];          // Welford on the raw (bias-free) value
+          mean[k] += d / cnt;
+          m2[k] += d * (v[k] - mean[k]);
+          if (c + k < Cout) {
+            float o = v[k] + (bias != nullptr ? bias[c + k] : 0.f);
+            float* dst = out + (int64_t)m * ldout + c + k;
+            if (accumulate) o += *dst;
+            *dst = o;
+          }
+        }
       }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { red[tid][k][0] = cnt; red[tid][k][1] = mean[k]; red[tid][k][2] = m2[k]; }
+      __syncthreads();
+      if (tid < gpb && g < G) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float n_ = red[tid][k][0], mu = red[tid][k][1], q = red[tid][k][2];
+          for (int w = 1; w < ppb; ++w) chan_combine(n_, mu, q, red[tid + w * gpb][k][0], red[tid + w * gpb][k][1], red[tid + w * gpb][k][2]);
+          if (c + k < Cout) {
+            float* st = stats + ((int64_t)blockIdx.x * Cout + c + k) * 2;
+            st[0] = mu;
+            st[1] = q;
+          }
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -347,7 +347,10 @@ template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
-  dim3 grid(a.ntile_m * a.ntile_n), block(WM * WN * 64);
+  const int niter_total = a.R * a.R * (a.Cin / BK);
+  a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
+  a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
+  dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(WM * WN * 64);
   const int lds_bytes = 3 * (BM + BN) * (BK + 4) * 4 + extra_lds;
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, ABL>;
   static int configured = 0;   // per instantiation
@@ -363,24 +366,49 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   return SSP_OK;
 }
 
-// Tile selection (shared by the launcher and by the host-side query that sizes the BN statistics workspace).
-// 128x128 is the workhorse; layers whose 128x128 grid would not fill the 512 resident-workgroup slots a few times over
-// (the 13x13 and 26x26 maps) use 64-row tiles to cut the last-wave imbalance; thin layers use 256-row tiles.
-static int select_bm(int M, int Cout) {
-  if (Cout > 64) {
-    const int64_t tiles128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
-    const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
-    if (variant == 20 || variant == 22) return 64;
-    if (variant == 0 && tiles128 <= 1400) return 64;
-    return 128;
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream);   // conv_igemm_dma.hip
+
+// Tile / split selection, a pure function of the layer shape (shared by the launcher and by the host-side queries
+// that size the BN-statistics and split-K workspaces).  128x128 tiles are the workhorse.  A grid that is not a whole
+// number of resident waves of workgroups (2 per CU = 512 slots for 128x128, 3 per CU = 768 for 64x128) idles the chip
+// in its last wave: the 13x13 layers (680 tiles) would run 2 waves at 66 %.  Those layers split the K loop
+// (ksplit workgroups per tile, partial tiles summed by splitk_reduce_kernel) so the grid becomes ~4 full waves;
+// mid-size grids use 64-row tiles instead.
+struct IgemmPlan { int bm, ksplit; };
+static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
+  IgemmPlan pl = {256, 1};
+  if (Cout <= 64) return pl;
+  pl.bm = 128;
+  const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
+  if (variant == 20 || variant == 22) { pl.bm = 64; return pl; }
+  if (variant != 0 && variant != 30 && variant != 50) return pl;   // experiment variants: plain 128x128, no split
+  const int64_t t128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
+  const int64_t t64 = (int64_t)ssp_cdiv(M, 64) * ssp_cdiv(Cout, 128);
+  if (t128 > 1400) return pl;
+  auto wave_eff = [](int64_t wgs, int slots) { return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots); };
+  double best = wave_eff(t128, 512);
+  const double e64 = 0.97 * wave_eff(t64, 768);
+  if (e64 > best) { best = e64; pl.bm = 64; }
+  if (variant == 30 || Cin % 16 != 0) return pl;            // variant 30: no split-K (A/B experiments)
+  const int niter = R * R * (Cin / 16);
+  const double flop_time = 2.0 * M * (double)Cout * R * R * Cin / 110e12;
+  for (int sp = 2; sp <= 6; ++sp) {
+    if (niter / sp < 24) break;
+    const double traffic = (2.0 * sp + 1.0) * (double)M * Cout * 4.0 / 4.0e12;   // partial writes + reads + final write
+    const double eff = wave_eff(t128 * sp, 512) / (1.0 + traffic / flop_time);
+    if (eff > best + 0.02) { best = eff; pl.bm = 128; pl.ksplit = sp; }
   }
-  return 256;
+  return pl;
 }
-int ssp_conv_tile_m(int M, int Cout) { return select_bm(M, Cout); }
+int ssp_conv_tile_m(int M, int Cin, int Cout, int R) { return select_plan(M, Cin, Cout, R).bm; }
+int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R) {
+  IgemmPlan pl = select_plan(M, Cin, Cout, R);
+  return pl.ksplit > 1 ? (int64_t)pl.ksplit * M * Cout : 0;
+}
 
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
-                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int prof_kind,
-                          hipStream_t stream) {
+                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
+                          int64_t ws_floats, int prof_kind, hipStream_t stream) {
   SSP_CHECK_ARG(R == 1 || R == 3, "conv: only 1x1 and 3x3 filters are supported (got %d)", R);
   SSP_CHECK_ARG(Cin % 4 == 0 && Cin > 0, "conv: Cin must be a positive multiple of 4 (got %d)", Cin);
   SSP_CHECK_ARG(ldin % 4 == 0 && ldin >= Cin, "conv: ldin must be a multiple of 4 and >= Cin");
@@ -392,11 +420,18 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
+  const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
+  a.ksplit = pl.ksplit;
+  a.ws = ws;
+  if (pl.ksplit > 1)
+    SSP_CHECK_ARG(ws != nullptr && ws_floats >= (int64_t)pl.ksplit * a.M * Cout,
+                  "conv: this shape runs split-K x%d and needs a workspace of %lld floats (ssp_conv_workspace_floats)",
+                  pl.ksplit, (long long)pl.ksplit * a.M * Cout);
   SspProfScope prof(prof_kind, stream, 2.0 * (double)a.M * Cout * (double)(R * R * Cin));
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);   // experiments: tools/conv_bench.py --opt igemm_variant=N
   const int bk = (Cin % 32 == 0 && (variant == 2 || variant == 4 || variant == 5)) ? 32 : ((Cin % 16 == 0) ? 16 : 4);
+  int rc = SSP_OK;
   if (Cout > 64) {
-    const int bm = select_bm(a.M, Cout);
     switch (variant) {
       case 3: if (bk >= 16) return launch_cfg<256, 128, 4, 2, 16>(a, stream); break;
       case 4: if (bk == 32) return launch_cfg<128, 128, 2, 2, 32, 1>(a, stream); break;
@@ -404,25 +439,36 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       case 10: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1>(a, stream); break;            // no loads
       case 14: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16>(a, stream); break;  // MFMA only
       case 17: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16 | 32>(a, stream); break;  // MFMA only, no epilogue
+      case 40: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 64>(a, stream); break;    // MFMA only + VALU probe
+      case 41: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 128>(a, stream); break;   // MFMA only + SALU probe
+      case 42: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 256>(a, stream); break;   // MFMA only + LDS-read probe
+      case 43: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 64 | 128 | 256>(a, stream); break;
       case 18: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 32>(a, stream); break;   // full loop, no epilogue
       case 21: if (bk >= 16) return launch_cfg<128, 64, 2, 2, 16>(a, stream); break;
       case 22: if (bk >= 16) return launch_cfg<64, 64, 2, 2, 16>(a, stream); break;
       default: break;
     }
-    if (bm == 64) {
-      if (bk >= 16) return launch_cfg<64, 128, 2, 2, 16>(a, stream);
-      return launch_cfg<64, 128, 2, 2, 4>(a, stream);
+    if (bk >= 16 && variant != 50 && ((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
+      rc = ssp_conv_igemm_dma_launch(a, pl.bm, stream);      // LDS-direct loader (conv_igemm_dma.hip)
+    } else if (pl.bm == 64) {
+      rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream);
+    } else if (bk == 32) {
+      rc = launch_cfg<128, 128, 2, 2, 32>(a, stream);
+    } else if (bk == 16) {
+      rc = launch_cfg<128, 128, 2, 2, 16>(a, stream);
+    } else {
+      rc = launch_cfg<128, 128, 2, 2, 4>(a, stream);
     }
-    if (bk == 32) return launch_cfg<128, 128, 2, 2, 32>(a, stream);
-    if (bk == 16) return launch_cfg<128, 128, 2, 2, 16>(a, stream);
-    return launch_cfg<128, 128, 2, 2, 4>(a, stream);
   } else if (Cout > 32) {
-    if (bk == 32) return launch_cfg<256, 64, 4, 1, 32>(a, stream);
-    if (bk == 16) return launch_cfg<256, 64, 4, 1, 16>(a, stream);
-    return launch_cfg<256, 64, 4, 1, 4>(a, stream);
+    rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else {
-    if (bk == 32) return launch_cfg<256, 32, 4, 1, 32>(a, stream);
-    if (bk == 16) return launch_cfg<256, 32, 4, 1, 16>(a, stream);
-    return launch_cfg<256, 32, 4, 1, 4>(a, stream);
+    rc = (bk >= 16) ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }
+  if (rc != SSP_OK) return rc;
+  if (pl.ksplit > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
+                       bias, stats, a.M, Cout, pl.bm, accumulate);
+    SSP_CHECK_LAUNCH("splitk_reduce");
+  }
+  return SSP_OK;
 }

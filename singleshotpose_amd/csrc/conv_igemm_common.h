@@ -1,0 +1,127 @@
+// ConvArgs + epilogue shared by conv_igemm.hip (register-staged loader) and conv_igemm_dma.hip (LDS-direct loader).
+#pragma once
+#include <type_traits>
+
+#include "ssp_common.h"
+
+struct ConvArgs {
+  const float* in;
+  const float* wt;
+  float* out;
+  const float* bias;  // [Cout] or nullptr (added in the epilogue; the linear head conv)
+  float* stats;       // [ntile_m][Cout][2] = per-M-tile (mean, M2) of the raw output, or nullptr
+  int H, W, Cin, Cout, ldin, ldout, R, M;
+  int accumulate;     // out += result (second consumer of a routed activation in dgrad)
+  int ntile_m, ntile_n;
+  int xcd_remap;
+  float* ws;           // split-K partial tiles [ksplit][M][Cout] (ksplit > 1)
+  int ksplit, it_per_split;
+};
+
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  float nt = n + nb;
+  if (nt > 0.f) {
+    float d = mb - mean;
+    float f = nb / nt;
+    mean += d * f;
+    m2 += m2b + d * d * n * f;
+    n = nt;
+  }
+}
+
+
+// Shared epilogue of the implicit-GEMM kernels.  C/D map of the 32x32 MFMA: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `smem` must be free (all LDS traffic of the K loop retired).
+template <int BM, int BN, int WM, int WN, int NT>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                               int m0, int n0, int tile_m, int split, int tid) {
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  if (p.ksplit > 1) {
+    // split-K: raw partial tile to the workspace; bias / accumulate / BN statistics happen in splitk_reduce_kernel
+    float* wsp = p.ws + (int64_t)split * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.Cout) wsp[(int64_t)m * p.Cout + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  auto body = [&](auto accum_tag) {
+    constexpr bool ACCUM = decltype(accum_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + li;
+      const bool n_ok = n < p.Cout;
+      const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+      float cnt = 0.f, sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int m = m0 + row;
+          float v = acc[i][j][r] + bias;
+          if (m < p.M && n_ok) {
+            float* o = p.out + (int64_t)m * p.ldout + n;
+            if constexpr (ACCUM) v += *o;
+            *o = v;
+            cnt += 1.f;
+            sum += acc[i][j][r];
+          }
+        }
+      }
+      if (p.stats != nullptr) {
+        // per-lane (count, mean, M2) of this lane's column over its valid rows, then Chan-combine:
+        // lane halves (rows +4) -> waves along M (through LDS) -> one (mean, M2) pair per column per M tile.
+        float mean = cnt > 0.f ? sum / cnt : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m0 + row < p.M && n_ok) {
+              float d = acc[i][j][r] - mean;
+              m2 += d * d;
+            }
+          }
+        }
+        float ocnt = __shfl_xor(cnt, 32), omean = __shfl_xor(mean, 32), om2 = __shfl_xor(m2, 32);
+        chan_combine(cnt, mean, m2, ocnt, omean, om2);
+        float* red = smem;  // [WM][BN][3]
+        int col = wn * WTN + j * 32 + li;
+        if (lh == 0) {
+          red[(wm * BN + col) * 3 + 0] = cnt;
+          red[(wm * BN + col) * 3 + 1] = mean;
+          red[(wm * BN + col) * 3 + 2] = m2;
+        }
+      }
+    }
+  };
+  if (p.accumulate) body(std::true_type{}); else body(std::false_type{});
+  if (p.stats != nullptr) {
+    __syncthreads();
+    for (int col = tid; col < BN; col += NT) {
+      int n = n0 + col;
+      if (n < p.Cout) {
+        float cnt = smem[col * 3 + 0], mean = smem[col * 3 + 1], m2 = smem[col * 3 + 2];
+#pragma unroll
+        for (int w = 1; w < WM; ++w)
+          chan_combine(cnt, mean, m2, smem[(w * BN + col) * 3 + 0], smem[(w * BN + col) * 3 + 1],
+                       smem[(w * BN + col) * 3 + 2]);
+        float* st = p.stats + ((int64_t)tile_m * p.Cout + n) * 2;
+        st[0] = mean;
+        st[1] = m2;
+      }
+    }
+  }
+}

@@ -1,0 +1,228 @@
+// Implicit-GEMM convolution, LDS-direct loader variant (the workhorse for Cin % 16 == 0, Cout > 64).
+//
+// Same contraction, tiles, MFMA and epilogue as conv_igemm.hip; what changes is how the operands reach the LDS.
+// On gfx950 the fp32 MFMA executes on the SIMD's vector lanes, so every VALU instruction in the K loop (address
+// arithmetic, v_cndmask zero-fill, register->LDS staging) steals matrix-core issue time one for one (measured:
+// 64 extra v_add per chunk = -11 %).  This kernel therefore moves ALL per-chunk loader work off the VALU:
+//
+//   * operands are fetched with `buffer_load_dwordx4 ... lds` (global -> LDS DMA, no VGPR staging, no ds_write);
+//   * the per-lane byte offset (`voffset`) is fixed for a whole filter tap and already encodes the image-border test:
+//     lanes whose tap falls outside the image (and rows beyond M / filters beyond Cout) carry an out-of-range offset,
+//     for which the buffer unit returns zeros - the zero padding costs no instruction;
+//   * the channel walk inside a tap is a scalar `soffset` increment; only a tap change (every Cin/16 chunks)
+//     recomputes the lane offsets;
+//   * an LDS-DMA image is lane-linear (1 KiB per wave-instruction, no row padding possible), so bank conflicts are
+//     removed by an XOR swizzle of the 16-byte chunk index with (row>>2)&3, applied on the SOURCE address of the load
+//     and on the fragment reads (cdna_hip_programming.md, rule 21);
+//   * 4-slot LDS ring, loads run 3 chunks ahead; one `s_waitcnt vmcnt(n)` + one raw `s_barrier` per chunk; the K loop
+//     is unrolled x4 so every LDS address is a register + immediate.
+#include "conv_igemm_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define SSP_OOB 0x80000000u   // >= num_records of the descriptors below: the load returns zeros
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
+  constexpr int BK = 16, WM = 2, WN = 2, NT = 256;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROWB = BK * 4;                  // bytes per tile row
+  constexpr int SLOTB = (BM + BN) * ROWB;       // bytes per ring slot: A rows then B rows
+  constexpr int NSLOT = 4;
+  constexpr int APW = BM / 64, BPW = BN / 64;   // 1-KiB wave-instructions per wave per chunk (16 rows each)
+  constexpr int LPW = APW + BPW;
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are dealt to the 4 waves in groups of 16");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // NSLOT * SLOTB bytes
+  char* const lds = reinterpret_cast<char*>(smem);
+
+  const int ntiles = p.ntile_m * p.ntile_n;
+  const int nwg = ntiles * p.ksplit;
+  const int lid0 = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+  const int split = lid0 / ntiles, lid = lid0 - split * ntiles;
+  const int tile_n = lid % p.ntile_n, tile_m = lid / p.ntile_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int pad = p.R >> 1;
+  const int K = p.R * p.R * p.Cin;
+  const int cpt = p.Cin / BK;
+  const int niter_all = p.R * p.R * cpt;
+  const int it_begin = split * p.it_per_split;
+  const int niter = min(niter_all, it_begin + p.it_per_split) - it_begin;
+
+  // ---- buffer descriptors: A starts (W+1) pixels before the tile so every tap offset is non-negative ----
+  const int halo = p.W + 1;
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + ((int64_t)m0 - halo) * p.ldin), 0, (int)SSP_OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + (int64_t)n0 * K), 0, (int)SSP_OOB, 0x00020000);
+
+  // ---- loader lanes: a wave-instruction covers 16 tile rows; lane -> (row = lane>>2, physical chunk = lane&3) ----
+  const int lrow = lane >> 2, lch = lane & 3;
+  int a_y[APW], a_x[APW];
+  unsigned a_row_off[APW], a_voff[APW], b_voff[BPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int row = (wid + 4 * j) * 16 + lrow;
+    const int m = m0 + row;
+    const int chunk = lch ^ ((row >> 2) & 3);              // logical 16-byte chunk stored at physical position lch
+    if (m < p.M) {
+      a_x[j] = m % p.W;
+      a_y[j] = (m / p.W) % p.H;
+    } else {
+      a_x[j] = 0;
+      a_y[j] = -(1 << 20);                                 // never inside the image
+    }
+    a_row_off[j] = (unsigned)((row + halo) * p.ldin + chunk * 4) * 4u;
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int row = (wid + 4 * j) * 16 + lrow;
+    const int chunk = lch ^ ((row >> 2) & 3);
+    b_voff[j] = (n0 + row < p.Cout) ? (unsigned)(row * K + chunk * 4) * 4u : SSP_OOB;
+  }
+
+  // ---- K-chunk walker (scalar): tap (dy,dx), channel offset, filter column; lane offsets recomputed per tap ----
+  int ld_tap = it_begin / cpt;
+  int ld_c0 = (it_begin - ld_tap * cpt) * BK;
+  int ld_koff = it_begin * BK;
+  auto set_tap = [&]() {
+    const int dy = ld_tap / p.R - pad, dx = ld_tap % p.R - pad;
+    const bool tap_ok = ld_tap < p.R * p.R;
+    const int shift = (dy * p.W + dx) * p.ldin * 4;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+      const bool ok = tap_ok && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+      a_voff[j] = ok ? (unsigned)((int)a_row_off[j] + shift) : SSP_OOB;
+    }
+  };
+  set_tap();
+  auto issue_loads = [&](int slot_bytes) {
+#pragma unroll
+    for (int j = 0; j < APW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds + slot_bytes + (wid + 4 * j) * 1024),
+                                               16, a_voff[j], ld_c0 * 4, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds + slot_bytes + BM * ROWB + (wid + 4 * j) * 1024),
+                                               16, b_voff[j], ld_koff * 4, 0, 0);
+    // advance; past the last chunk the filter column is clamped and the tap index runs out of range (all lanes OOB)
+    ld_koff = min(ld_koff + BK, K - BK);
+    ld_c0 += BK;
+    if (ld_c0 == p.Cin) {
+      ld_c0 = 0;
+      ++ld_tap;
+      set_tap();
+    }
+  };
+
+  // ---- fragment addressing: lane (i,h) reads logical chunk 2q+h of its row, stored at chunk ^ ((row>>2)&3) ----
+  unsigned fa_off[TM][2], fb_off[TN][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const unsigned ch = (unsigned)((2 * q + lh) ^ ((li >> 2) & 3)) * 16u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa_off[i][q] = (unsigned)(wm * WTM + i * 32 + li) * ROWB + ch;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb_off[j][q] = (unsigned)(BM + wn * WTN + j * 32 + li) * ROWB + ch;
+  }
+  auto read_frag = [&](int slot_bytes, int q, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(lds + slot_bytes + fa_off[i][q]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(lds + slot_bytes + fb_off[j][q]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- prologue: chunks 0,1,2 in flight, wait for all, publish ----
+  issue_loads(0 * SLOTB);
+  issue_loads(1 * SLOTB);
+  issue_loads(2 * SLOTB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  read_frag(0, 0, fa0, fb0);
+
+  // one K chunk; S = ring slot of the chunk being multiplied (compile time: LDS addresses become immediates)
+  auto step = [&](auto slot_tag) {
+    constexpr int S = decltype(slot_tag)::value;
+    constexpr int S1 = (S + 1) % NSLOT, S3 = (S + 3) % NSLOT;
+    issue_loads(S3 * SLOTB);                 // chunk it+3 (slot last read one barrier ago)
+    read_frag(S * SLOTB, 1, fa1, fb1);
+    mma(fa0, fb0);
+    read_frag(S1 * SLOTB, 0, fa0, fb0);      // chunk it+1 was published by the previous barrier
+    mma(fa1, fb1);
+    // chunk it+2 (issued one step ago) must have landed before it is published; this step's LPW loads stay in flight
+    if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (LPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  int it = 0;
+  for (; it + 4 <= niter; it += 4) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+  }
+  if (it < niter) { step(std::integral_constant<int, 0>{}); ++it; }
+  if (it < niter) { step(std::integral_constant<int, 1>{}); ++it; }
+  if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
+
+  // retire the run-ahead DMA before the LDS is reused by the epilogue
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid);
+#endif
+}
+
+template <int BM, int BN>
+static int launch_dma(ConvArgs a, hipStream_t stream) {
+  a.ntile_m = ssp_cdiv(a.M, BM);
+  a.ntile_n = ssp_cdiv(a.Cout, BN);
+  const int niter_total = a.R * a.R * (a.Cin / 16);
+  a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
+  a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
+  dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);
+  const int lds_bytes = 4 * (BM + BN) * 64;
+  auto kern = conv_igemm_dma_kernel<BM, BN>;
+  static int configured = 0;
+  if (lds_bytes > configured) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      ssp_set_error("conv_igemm_dma: cannot reserve %d bytes of LDS", lds_bytes);
+      return SSP_ERR_HIP;
+    }
+    configured = lds_bytes;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+  SSP_CHECK_LAUNCH("conv_igemm_dma");
+  return SSP_OK;
+}
+
+// bm in {64, 128}; BN = 128.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
+// ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream) {
+  return bm == 64 ? launch_dma<64, 128>(a, stream) : launch_dma<128, 128>(a, stream);
+}

@@ -319,27 +319,42 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
   a.ntile_co = ssp_cdiv(a.Cout, BMO);
   a.ntile_ci = ssp_cdiv(a.Cin, BNI);
   const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * a.R * a.R;
-  // enough workgroups for ~6 per CU, but keep >= 8 staging iterations per workgroup
-  int64_t want = (1536 + tiles - 1) / tiles;
-  int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);
-  int64_t nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
-  if (nsplit < 1) nsplit = 1;
-  int64_t chunk = (a.M + nsplit - 1) / nsplit;
-  chunk = (chunk + RA - 1) / RA * RA;
-  nsplit = (a.M + chunk - 1) / chunk;
-  a.nsplit = (int)nsplit;
-  a.chunk_m = (int)chunk;
-  dim3 grid((unsigned)(tiles * nsplit)), block(256);
   const int lds_bytes = 3 * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_kernel<BMO, BNI, WM, WN, WK>;
   static int configured = 0;
+  static int slots = 0;   // workgroups resident on the whole chip (occupancy x 256 CUs)
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
       ssp_set_error("conv_wgrad: cannot reserve %d bytes of LDS", lds_bytes);
       return SSP_ERR_HIP;
     }
     configured = lds_bytes;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 2;
+    slots = per_cu * 256;
   }
+  // Split the pixel reduction so that the grid is (close to) a whole number of resident waves of workgroups - a
+  // 2.25-wave grid runs as long as a 3-wave one - with 2..5 waves in total and >= 8 staged chunks per workgroup.
+  const int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);
+  int64_t lo = (2 * (int64_t)slots + tiles - 1) / tiles, hi = (5 * (int64_t)slots) / tiles;
+  if (lo < 1) lo = 1;
+  if (hi < lo) hi = lo;
+  if (lo > max_split) lo = max_split;
+  if (hi > max_split) hi = max_split;
+  int64_t nsplit = lo;
+  double best = -1.0;
+  for (int64_t sp = lo; sp <= hi; ++sp) {
+    const double waves = (double)(tiles * sp) / slots;
+    const double eff = waves / (double)((tiles * sp + slots - 1) / slots);
+    if (eff > best + 1e-3) { best = eff; nsplit = sp; }
+  }
+  int64_t chunk = (a.M + nsplit - 1) / nsplit;
+  chunk = (chunk + RA - 1) / RA * RA;
+  nsplit = (a.M + chunk - 1) / chunk;
+  a.nsplit = (int)nsplit;
+  a.chunk_m = (int)chunk;
+  dim3 grid((unsigned)(tiles * nsplit)), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_wgrad");
   return SSP_OK;

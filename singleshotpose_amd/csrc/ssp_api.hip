@@ -8,10 +8,11 @@
 #include "ssp_common.h"
 
 // ---- kernels' host launchers (defined next to the kernels) ----
-int ssp_conv_tile_m(int M, int Cout);
+int ssp_conv_tile_m(int M, int Cin, int Cout, int R);
+int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R);
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
-                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int prof_kind,
-                          hipStream_t stream);
+                          int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
+                          int64_t ws_floats, int prof_kind, hipStream_t stream);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
@@ -115,16 +116,22 @@ int ssp_set_option(const char* name, int value) {
 }
 
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
-                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, void* stream) {
-  return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate,
-                               SSP_PROF_CONV_FWD, (hipStream_t)stream);
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* workspace,
+                 int64_t workspace_floats, void* stream) {
+  return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate, workspace,
+                               workspace_floats, SSP_PROF_CONV_FWD, (hipStream_t)stream);
 }
-int ssp_conv_stats_tile_m(int B, int H, int W, int Cout) { return ssp_conv_tile_m(B * H * W, Cout); }
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R) {
+  return ssp_conv_tile_m(B * H * W, Cin, Cout, R);
+}
+int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R) {
+  return ssp_conv_ws_floats(B * H * W, Cin, Cout, R);
+}
 
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
-                   int lddx, int R, int accumulate, void* stream) {
+                   int lddx, int R, int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
   return ssp_conv_igemm_launch(dy, wt, dx, nullptr, nullptr, B, H, W, Cout_dy, Cin_dx, lddy, lddx, R, accumulate,
-                               SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
+                               workspace, workspace_floats, SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
 }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,

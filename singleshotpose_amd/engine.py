@@ -131,7 +131,9 @@ class Plan(object):
                     cs.out = _Act(alloc(B * Ho * Wo * cs.coutp, **f32), 0, c, Ho, Wo, cs.coutp)
                 else:
                     cs.out = _Act(cs.raw, 0, c, cs.H, cs.W, cs.coutp)
-                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, c)
+                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, c, k)
+                cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, c, k)
+                cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, k)
                 cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
                 if cs.bn:
                     cs.stats = torch.empty(cs.ntile * c * 2, **f32)
@@ -191,6 +193,9 @@ class Plan(object):
         self.dpack = torch.empty(max(dsz, 1), **f32)
         self.gpack = torch.empty(max(wsz, 1), **f32)   # packed filter gradients (zeroed each backward)
         self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
+        # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
+        self.ws_floats = max([1] + [max(cs.ws_fwd, cs.ws_dgrad) for cs in self.convs.values()])
+        self.ws = torch.empty(self.ws_floats, **f32)
         self.wversion = {}
         self.generation = 0
         # flat gradient buffer layout, in backward (reverse layer) order so that all-reduce buckets close early:
@@ -236,7 +241,7 @@ class Plan(object):
                 use_stats = cs.bn and training
                 call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(), bias,
                      cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
-                     cs.k, 0, st)
+                     cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
                 v = cs.vec
                 if cs.bn:
                     bn = cs.bnm
@@ -365,7 +370,7 @@ class Plan(object):
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
                     call('ssp_conv_dgrad', dy_ptr, _ptr(self.dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
-                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, st)
+                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, self.ws.data_ptr(), self.ws_floats, st)
                     written.add(src)
             elif t == 'maxpool':
                 if ind not in written:

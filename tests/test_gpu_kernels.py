@@ -30,6 +30,8 @@ CONV_CASES = [
     (2, 13, 13, 48, 160, 3, 16, 32, False),  # channel slices of wider buffers; Cout not a tile multiple
     (1, 26, 26, 20, 1024, 3, 0, 0, False),   # K chunk of 4 (Cin % 16 != 0), many N tiles
     (5, 13, 13, 256, 256, 3, 0, 0, False),   # several M tiles + ragged M
+    (64, 13, 13, 128, 1024, 3, 0, 0, False), # 680 tiles: split-K path + splitk_reduce statistics
+    (64, 13, 13, 64, 1024, 3, 0, 32, True),  # split-K with bias and a sliced output
 ]
 
 
@@ -50,11 +52,13 @@ def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
     wd = G.pack_fwd(w, cinp)
     out = torch.full((B * H * W, ldout), float('nan'), dtype=torch.float32, device=G.dev())
     bd = bvec.to(G.dev()) if bias else None
-    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cout)
+    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, cinp, Cout, R)
+    wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R))
+    ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
     ntile = (B * H * W + tile_m - 1) // tile_m
     stats = torch.zeros(ntile * Cout * 2, dtype=torch.float32, device=G.dev())
     _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
-              stats.data_ptr(), B, H, W, cinp, Cout, ldin, ldout, R, 0, G.stream())
+              stats.data_ptr(), B, H, W, cinp, Cout, ldin, ldout, R, 0, ws.data_ptr(), wsn, G.stream())
     torch.cuda.synchronize()
     got = G.from_nhwc(out, B, Cout, H, W, xout_off)
     assert rel_err(got.numpy(), ref.numpy()) < TOL
@@ -64,7 +68,7 @@ def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
         assert torch.isnan(o[:, :xout_off]).all() and torch.isnan(o[:, xout_off + Cout:]).all()
     # accumulate mode
     _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
-              None, B, H, W, cinp, Cout, ldin, ldout, R, 1, G.stream())
+              None, B, H, W, cinp, Cout, ldin, ldout, R, 1, ws.data_ptr(), wsn, G.stream())
     torch.cuda.synchronize()
     got2 = G.from_nhwc(out, B, Cout, H, W, xout_off)
     assert rel_err(got2.numpy(), (2 * ref).numpy()) < TOL
@@ -101,6 +105,7 @@ GRAD_CASES = [
     (2, 12, 12, 32, 64, 3),     # 64x32 wgrad tile with in-workgroup K split
     (4, 13, 13, 256, 256, 3),
     (2, 26, 26, 512, 64, 1),
+    (64, 13, 13, 64, 512, 3),   # dgrad/wgrad at the 13x13 benchmark grid (split-K dgrad)
 ]
 
 
@@ -130,7 +135,9 @@ def test_conv_dgrad_wgrad(B, H, W, Cin, Cout, R):
     if Cin % 4 == 0:
         wd = G.pack_dgrad(w.detach(), coutp)
         dx = torch.full((B * H * W, Cin), float('nan'), dtype=torch.float32, device=G.dev())
-        _lib.call('ssp_conv_dgrad', dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin, coutp, Cin, R, 0, G.stream())
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R))
+        ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+        _lib.call('ssp_conv_dgrad', dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin, coutp, Cin, R, 0, ws.data_ptr(), wsn, G.stream())
         torch.cuda.synchronize()
         assert rel_err(G.from_nhwc(dx, B, Cin, H, W).numpy(), x.grad.numpy()) < TOL
 
@@ -266,4 +273,4 @@ def test_colsum():
 def test_error_reporting():
     G, _lib = _imports()
     with pytest.raises(_lib.SspError, match="1x1 and 3x3"):
-        _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, G.stream())
+        _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, None, 0, G.stream())
