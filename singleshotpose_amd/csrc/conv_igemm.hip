@@ -377,7 +377,10 @@ int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream);   
 struct IgemmPlan { int bm, ksplit; };
 static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
   IgemmPlan pl = {256, 1};
-  if (Cout <= 64) return pl;
+  if (Cout <= 64) {
+    if (Cout > 32 && Cin % 16 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50) pl.bm = 128;   // 128x64 LDS-direct tiles
+    return pl;
+  }
   pl.bm = 128;
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
   if (variant == 20 || variant == 22) { pl.bm = 64; return pl; }
@@ -393,7 +396,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
   const int niter = R * R * (Cin / 16);
   const double flop_time = 2.0 * M * (double)Cout * R * R * Cin / 110e12;
   for (int sp = 2; sp <= 6; ++sp) {
-    if (niter / sp < 24) break;
+    if (niter / sp < 128) break;   // short K per workgroup: prologue/epilogue and the reduce pass eat the gain (measured)
     const double traffic = (2.0 * sp + 1.0) * (double)M * Cout * 4.0 / 4.0e12;   // partial writes + reads + final write
     const double eff = wave_eff(t128 * sp, 512) / (1.0 + traffic / flop_time);
     if (eff > best + 0.02) { best = eff; pl.bm = 128; pl.ksplit = sp; }
@@ -460,7 +463,12 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       rc = launch_cfg<128, 128, 2, 2, 4>(a, stream);
     }
   } else if (Cout > 32) {
-    rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
+    if (pl.bm == 128) {
+      SSP_CHECK_ARG((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31),
+                    "conv: image rows too long for the 32-bit tile offsets of the LDS-direct loader");
+      rc = ssp_conv_igemm_dma_launch(a, 128, stream);
+    } else
+      rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else {
     rc = (bk >= 16) ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }

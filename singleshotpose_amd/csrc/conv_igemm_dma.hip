@@ -161,20 +161,27 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
   issue_loads(2 * SLOTB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  read_frag(0, 0, fa0, fb0);
+  // fragment registers: q = 0 fragments ping-pong between two sets (step parity) so that the NEXT chunk's first
+  // fragments can be fetched at the top of a step, a full chunk of MFMAs before they are needed
+  f32x4 fa0[2][TM], fb0[2][TN], fa1[TM], fb1[TN];
+  read_frag(0, 0, fa0[0], fb0[0]);
 
   // one K chunk; S = ring slot of the chunk being multiplied (compile time: LDS addresses become immediates)
   auto step = [&](auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     constexpr int S1 = (S + 1) % NSLOT, S3 = (S + 3) % NSLOT;
+    constexpr int P = S & 1;                 // NSLOT is even: slot parity == step parity
     issue_loads(S3 * SLOTB);                 // chunk it+3 (slot last read one barrier ago)
     read_frag(S * SLOTB, 1, fa1, fb1);
-    mma(fa0, fb0);
-    read_frag(S1 * SLOTB, 0, fa0, fb0);      // chunk it+1 was published by the previous barrier
+    read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // chunk it+1 was published by the previous barrier
+    __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads up here (the scheduler would sink them to their use)
+    mma(fa0[P], fb0[P]);
     mma(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);       // ... and the wait + barrier below the MFMAs (MFMAs are register-only, so
+                                             // the scheduler is otherwise free to hoist the barrier above them)
     // chunk it+2 (issued one step ago) must have landed before it is published; this step's LPW loads stay in flight
-    if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if constexpr (LPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (LPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -221,8 +228,9 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   return SSP_OK;
 }
 
-// bm in {64, 128}; BN = 128.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
+// bm in {64, 128} with BN = 128, or 128 x 64 tiles for Cout <= 64.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
 int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream) {
+  if (a.Cout <= 64) return launch_dma<128, 64>(a, stream);
   return bm == 64 ? launch_dma<64, 128>(a, stream) : launch_dma<128, 128>(a, stream);
 }
