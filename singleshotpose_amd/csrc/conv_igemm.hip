@@ -366,7 +366,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   return SSP_OK;
 }
 
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream);   // conv_igemm_dma.hip
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream_t stream);   // conv_igemm_dma.hip
 
 // Tile / split selection, a pure function of the layer shape (shared by the launcher and by the host-side queries
 // that size the BN-statistics and split-K workspaces).  128x128 tiles are the workhorse.  A grid that is not a whole
@@ -452,7 +452,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       default: break;
     }
     if (bk >= 16 && variant != 50 && ((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
-      rc = ssp_conv_igemm_dma_launch(a, pl.bm, stream);      // LDS-direct loader (conv_igemm_dma.hip)
+      rc = ssp_conv_igemm_dma_launch(a, pl.bm, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
     } else if (pl.bm == 64) {
       rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream);
     } else if (bk == 32) {
@@ -466,7 +466,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     if (pl.bm == 128) {
       SSP_CHECK_ARG((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31),
                     "conv: image rows too long for the 32-bit tile offsets of the LDS-direct loader");
-      rc = ssp_conv_igemm_dma_launch(a, 128, stream);
+      rc = ssp_conv_igemm_dma_launch(a, 128, prof_kind == SSP_PROF_CONV_DGRAD, stream);
     } else
       rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else {

@@ -22,7 +22,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define SSP_OOB 0x80000000u   // >= num_records of the descriptors below: the load returns zeros
 
-template <int BM, int BN>
+// PASS (0 = forward, 1 = data gradient) does not change the code: it gives the two uses distinct kernel names, so a
+// profile can tell the forward launches (exclusive on the GPU) from the dgrad launches (which overlap wgrad on a
+// second stream in Plan.backward).
+template <int BM, int BN, int PASS>
 __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
   constexpr int BK = 16, WM = 2, WN = 2, NT = 256;
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
 #endif
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PASS>
 static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
@@ -214,7 +217,7 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);
   const int lds_bytes = 4 * (BM + BN) * 64;
-  auto kern = conv_igemm_dma_kernel<BM, BN>;
+  auto kern = conv_igemm_dma_kernel<BM, BN, PASS>;
   static int configured = 0;
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
@@ -230,7 +233,11 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
 
 // bm in {64, 128} with BN = 128, or 128 x 64 tiles for Cout <= 64.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, hipStream_t stream) {
-  if (a.Cout <= 64) return launch_dma<128, 64>(a, stream);
-  return bm == 64 ? launch_dma<64, 128>(a, stream) : launch_dma<128, 128>(a, stream);
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream_t stream) {
+  if (is_dgrad) {
+    if (a.Cout <= 64) return launch_dma<128, 64, 1>(a, stream);
+    return bm == 64 ? launch_dma<64, 128, 1>(a, stream) : launch_dma<128, 128, 1>(a, stream);
+  }
+  if (a.Cout <= 64) return launch_dma<128, 64, 0>(a, stream);
+  return bm == 64 ? launch_dma<64, 128, 0>(a, stream) : launch_dma<128, 128, 0>(a, stream);
 }

@@ -216,6 +216,7 @@ class Plan(object):
             cs.grad_hi = goff
         self.grad_total = goff
         self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
+        self.side_stream = None
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
         self.consumed = False
@@ -304,10 +305,18 @@ class Plan(object):
             raise NotImplementedError("network output channels must be a multiple of 4")
         written.add(self.last)
         self.gpack.zero_()
+        # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
+        # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        side = self.side_stream
+        st2 = side.cuda_stream
+        main = torch.cuda.current_stream()
         out_grads = {}
         training = self.was_training
         # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
         flat = torch.empty(self.grad_total, dtype=torch.float32, device=self.device)
+        flat.record_stream(side)
         self.last_flat_grad = flat
 
         def gview(prm):
@@ -356,13 +365,15 @@ class Plan(object):
                     db = gview(cs.conv.bias)
                     call('ssp_colsum', dy_ptr, dy_ld, cs.M, cs.cout, db.data_ptr(), st)
                     out_grads[id(cs.conv.bias)] = db
+                side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
                 call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp, cs.cout,
-                     dy_ld, cs.inp.ld, cs.k, st)
+                     dy_ld, cs.inp.ld, cs.k, st2)
                 gw = gview(cs.conv.weight)
-                call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st)
+                call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
                 out_grads[id(cs.conv.weight)] = gw
                 if self.reducer is not None:
-                    self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
+                    with torch.cuda.stream(side):   # the all-reduce of a finished bucket is ordered after its wgrads
+                        self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
                 if not cs.first:
                     wt = cs.conv.weight
                     call('ssp_repack_dgrad', wt.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp,
@@ -409,6 +420,7 @@ class Plan(object):
                              1 if src in written else 0, st)
                     written.add(src)
                     off += a.C
+        main.wait_stream(side)                  # every filter gradient is complete before autograd hands them out
         return out_grads
 
 
