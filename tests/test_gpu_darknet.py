@@ -144,3 +144,67 @@ def test_cpu_input_raises():
     m = Darknet(os.path.join(GOLD, 'tiny-pose.cfg'))
     with pytest.raises(RuntimeError, match="HIP"):
         m(torch.zeros(1, 3, 96, 96))
+
+
+def test_inference_pipeline_672():
+    """valid.py's path (valid.py:107-153): eval forward at the 672x672 test size, get_region_boxes, PnP."""
+    from oracle.darknet_ref import forward_ref
+    from oracle.pnp_ref import project, solve_pnp_ref
+    from oracle.region_loss_ref import get_region_boxes_ref
+    from singleshotpose_amd.utils import get_camera_intrinsic, get_region_boxes, pnp
+    model, state = _build(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 17)
+    assert (model.test_width, model.test_height) == (672, 672)
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.uniform(0, 1, (1, 3, 672, 672)).astype(np.float32))
+    model.eval()
+    with torch.no_grad():
+        out = model(x.cuda())
+        ref = forward_ref(model.blocks, clone_state(state), x, training=False)
+    assert tuple(out.shape) == (1, 20, 21, 21)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+    box = get_region_boxes(out, 1, 9)
+    box_ref = get_region_boxes_ref(ref, 1, 9)
+    np.testing.assert_allclose(np.array([float(v) for v in box]), np.array(box_ref, dtype=np.float64), rtol=2e-4, atol=2e-5)
+    corners2d = np.array(np.reshape([float(v) for v in box[:18]], [9, 2]), dtype='float32')
+    corners2d[:, 0] *= 640
+    corners2d[:, 1] *= 480
+    K = np.array(get_camera_intrinsic(325.2611, 242.0489, 572.4114, 573.5704), dtype='float32')
+    X = np.concatenate([np.zeros((1, 3)), np.array([[sx * .038, sy * .039, sz * .046] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])], 0).astype('float32')
+    R, t = pnp(X, corners2d, K)
+    R_o, t_o = solve_pnp_ref(X, corners2d, K)
+    assert R.shape == (3, 3) and t.shape == (3, 1)
+    # random-weight corners are not a rigid projection: both solvers must land on the same least-squares pose
+    assert np.abs(project(X, R, t, K) - project(X, R_o, t_o, K)).max() < 1e-2
+
+
+def test_multi_object_train_step():
+    """yolo-pose-multi style head (5 anchors x 13 classes) on the tiny trunk: forward, multi RegionLoss, backward."""
+    from oracle.darknet_ref import forward_ref, seeded_state
+    from oracle.region_loss_ref import region_loss_ref
+    from singleshotpose_amd.darknet import DarknetMulti
+    from singleshotpose_amd.region_loss import RegionLossMulti
+    cfg = os.path.join(GOLD, 'tiny-pose-multi.cfg')
+    model = DarknetMulti(cfg)
+    state = seeded_state(model.blocks, 23)
+    load_state_into(model, model.blocks, state)
+    model = model.cuda().train()
+    assert isinstance(model.models[-1], RegionLossMulti) and model.num_anchors == 5 and model.num_classes == 13
+    rs = np.random.RandomState(6)
+    B = 4
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, 96, 96)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [2, 1, 3, 1], multi=True))
+    crit = RegionLossMulti(num_keypoints=9, num_classes=13, anchors=model.anchors, num_anchors=5, pretrain_num_epochs=0)
+    crit.verbose = False
+    out = model(x.cuda())
+    assert tuple(out.shape) == (B, 160, 3, 3)
+    loss = crit(out, tgt, 1)
+    loss.backward()
+    st = clone_state(state, requires_grad=True)
+    y = forward_ref(model.blocks, st, x, training=True)
+    r = region_loss_ref(y.detach(), tgt, 1, num_classes=13, num_anchors=5, anchors=model.anchors, pretrain_num_epochs=0, multi=True)
+    y.backward(r['grad'])
+    assert rel_err(out.detach().cpu().numpy(), y.detach().numpy()) < TOL
+    assert abs(float(loss) - r['loss']) <= TOL * abs(r['loss'])
+    for ind, e in enumerate(st):
+        if e is not None:
+            assert rel_err(model.models[ind][0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 3e-4, ind
