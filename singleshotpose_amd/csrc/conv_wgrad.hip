@@ -360,6 +360,9 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
   return SSP_OK;
 }
 
+int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                           int ldx, int R, hipStream_t stream);   // conv_wgrad_dma.hip
+
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout,
                           int lddy, int ldx, int R, hipStream_t stream) {
   SSP_CHECK_ARG(R == 1 || R == 3, "wgrad: only 1x1 and 3x3 filters are supported (got %d)", R);
@@ -372,6 +375,10 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = B * H * W;
   SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)a.M * Cout * (double)(R * R * Cin));
+  if (ssp_option(SSP_OPT_WGRAD_VARIANT) != 2) {   // LDS-direct loader for tiles with >= 64 couts and >= 64 cins
+    const int r = ssp_conv_wgrad_dma_try(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, R, stream);
+    if (r != 0) return r < 0 ? r : SSP_OK;
+  }
   if (Cin == 4 && Cout == 32 && R == 3 && ldx == 4 && ssp_option(SSP_OPT_WGRAD_VARIANT) != 1) {
     // ~8 workgroups per CU, each a multiple of 64 pixels
     int64_t chunk = (a.M + 2047) / 2048;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--B', type=int, default=64)
     ap.add_argument('--opt', default='', help='name=value,... passed to ssp_set_option')
+    ap.add_argument('--wvariants', default='', help='comma list of wgrad_variant values to loop over')
     ap.add_argument('--variants', default='', help='comma list: run every case once per igemm_variant value')
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(',')):
@@ -35,6 +36,12 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     B = args.B
     variants = [int(v) for v in args.variants.split(',')] if args.variants else [None]
+    if args.wvariants:
+        for wv in [int(v) for v in args.wvariants.split(',')]:
+            _lib.call('ssp_set_option', b'wgrad_variant', wv)
+            print('WGRAD VARIANT', wv, flush=True)
+            run_cases(args, dev, st, B)
+        return
     for variant in variants:
       if variant is not None:
         _lib.call('ssp_set_option', b'igemm_variant', variant)
