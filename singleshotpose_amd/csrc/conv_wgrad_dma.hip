@@ -243,6 +243,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                            int ldx, int R, hipStream_t stream) {
   if (Cout < 64 || Cin < 64) return 0;
+  if (W < 8) return 0;   // the per-lane pixel walker advances 16 pixels with at most two row wraps
   const int64_t M = (int64_t)B * H * W;
   // 32-bit lane offsets: 16 staged rows of the widest operand, and the whole dY range of a workgroup
   if ((int64_t)16 * lddy * 4 >= (1ll << 31) || (int64_t)16 * ldx * 4 >= (1ll << 31)) return 0;

@@ -98,7 +98,7 @@ def pnp_batched(points_3D, points_2D, cameraMatrix, max_iter=20):
     K = np.asarray(cameraMatrix, dtype=np.float64)
     if K.ndim == 2:
         K = np.broadcast_to(K, (n, 3, 3))
-    Kt = torch.as_tensor(np.array(K, dtype=np.float64, copy=True))
+    Kt = torch.as_tensor(np.array(K, dtype=np.float64, order='C', copy=True)).contiguous()
     if not torch.cuda.is_available():
         raise RuntimeError("pnp runs on the MI355X HIP kernel only (no CPU fallback; cv2 is not used)")
     dev = torch.device('cuda', torch.cuda.current_device())

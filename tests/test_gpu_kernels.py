@@ -106,6 +106,8 @@ GRAD_CASES = [
     (4, 13, 13, 256, 256, 3),
     (2, 26, 26, 512, 64, 1),
     (64, 13, 13, 64, 512, 3),   # dgrad/wgrad at the 13x13 benchmark grid (split-K dgrad)
+    (4, 3, 3, 64, 64, 3),       # tiny maps: fewer pixels than one staged chunk, W < 8
+    (3, 9, 11, 128, 64, 3),     # W < 16: the LDS-direct wgrad loader wraps image rows twice per chunk
 ]
 
 
