@@ -284,61 +284,58 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
 
 // Sum of the split-K partial tiles: out[m][n] (+)= sum_s ws[s][m][n] + bias[n], and - for BN layers - the per-row-tile
 // (mean, M2) statistics in the same format the conv epilogue emits (tile_m rows per tile).  HBM-bound: reads
-// ksplit*M*Cout floats once, writes M*Cout.  One workgroup per row tile; thread = 4 channels x a row lane.
+// ksplit*M*Cout floats once, writes M*Cout.  Grid = (row tiles, 64-channel slabs); thread = one float4 of channels
+// (16 per slab) x one of 16 row lanes; Welford per thread, Chan-combine of the 16 row lanes through LDS.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
                                                             const float* __restrict__ bias, float* stats, int M,
                                                             int Cout, int tile_m, int accumulate) {
-  const int G = (Cout + 3) >> 2;
-  const int gpb = G < 256 ? G : 256, ppb = 256 / gpb;
-  const int tid = threadIdx.x, gl = tid % gpb, pp = tid / gpb;
+  const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
+  const int c = blockIdx.y * 64 + gl * 4;
   const int m0 = blockIdx.x * tile_m, m1 = min(M, m0 + tile_m);
-  __shared__ float red[256][4][3];
-  for (int g0 = 0; g0 < G; g0 += gpb) {
-    const int g = g0 + gl;
-    const int c = g * 4;
-    const bool active = (pp < ppb) && (g < G);
-    float cnt = 0.f, mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-      for (int m = m0 + pp; m < m1; m += ppb) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < ksplit; ++sp) {
-          const float* src = ws + ((int64_t)sp * M + m) * Cout + c;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (c + k < Cout) v[k] += src[k];
-        }
-        cnt += 1.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float d = v[k] - mean[k];          // Welford on the raw (bias-free) value
-          mean[k] += d / cnt;
-          m2[k] += d * (v[k] - mean[k]);
-          if (c + k < Cout) {
-            float o = v[k] + (bias != nullptr ? bias[c + k] : 0.f);
-            float* dst = out + (int64_t)m * ldout + c + k;
-            if (accumulate) o += *dst;
-            *dst = o;
-          }
-        }
+  const bool cok = c < Cout;           // Cout % 4 == 0 on this path (checked by the launcher)
+  float cnt = 0.f;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (cok && bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(bias + c);
+  if (cok) {
+    for (int m = m0 + pp; m < m1; m += 16) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
+      for (int sp = 1; sp < ksplit; ++sp) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * M + m) * Cout + c);
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
       }
+      cnt += 1.f;
+      const float inv = 1.f / cnt;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = v[k] - mean[k];     // Welford on the raw (bias-free) value
+        mean[k] += d * inv;
+        m2[k] += d * (v[k] - mean[k]);
+      }
+      float* dst = out + (int64_t)m * ldout + c;
+      f32x4 o = {v[0] + b4[0], v[1] + b4[1], v[2] + b4[2], v[3] + b4[3]};
+      if (accumulate) {
+        const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
+        o[0] += prev[0]; o[1] += prev[1]; o[2] += prev[2]; o[3] += prev[3];
+      }
+      *reinterpret_cast<f32x4*>(dst) = o;
     }
-    if (stats != nullptr) {
+  }
+  if (stats == nullptr) return;
+  __shared__ float red[16][16][9];   // [row lane][channel quad][cnt, mean x4, m2 x4]
+  red[pp][gl][0] = cnt;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { red[tid][k][0] = cnt; red[tid][k][1] = mean[k]; red[tid][k][2] = m2[k]; }
-      __syncthreads();
-      if (tid < gpb && g < G) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float n_ = red[tid][k][0], mu = red[tid][k][1], q = red[tid][k][2];
-          for (int w = 1; w < ppb; ++w) chan_combine(n_, mu, q, red[tid + w * gpb][k][0], red[tid + w * gpb][k][1], red[tid + w * gpb][k][2]);
-          if (c + k < Cout) {
-            float* st = stats + ((int64_t)blockIdx.x * Cout + c + k) * 2;
-            st[0] = mu;
-            st[1] = q;
-          }
-        }
-      }
-      __syncthreads();
+  for (int k = 0; k < 4; ++k) { red[pp][gl][1 + k] = mean[k]; red[pp][gl][5 + k] = m2[k]; }
+  __syncthreads();
+  if (tid < 64) {                     // one thread per channel of the slab
+    const int q = tid >> 2, k = tid & 3;
+    const int ch = blockIdx.y * 64 + tid;
+    if (ch < Cout) {
+      float n_ = red[0][q][0], mu = red[0][q][1 + k], s2 = red[0][q][5 + k];
+      for (int w = 1; w < 16; ++w) chan_combine(n_, mu, s2, red[w][q][0], red[w][q][1 + k], red[w][q][5 + k]);
+      float* st = stats + ((int64_t)blockIdx.x * Cout + ch) * 2;
+      st[0] = mu;
+      st[1] = s2;
     }
   }
 }
@@ -392,7 +389,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
   double best = wave_eff(t128, 512);
   const double e64 = 0.97 * wave_eff(t64, 768);
   if (e64 > best) { best = e64; pl.bm = 64; }
-  if (variant == 30 || Cin % 16 != 0) return pl;            // variant 30: no split-K (A/B experiments)
+  if (variant == 30 || Cin % 16 != 0 || Cout % 4 != 0) return pl;   // variant 30: no split-K (A/B experiments)
   const int niter = R * R * (Cin / 16);
   const double flop_time = 2.0 * M * (double)Cout * R * R * Cin / 110e12;
   for (int sp = 2; sp <= 6; ++sp) {
@@ -426,6 +423,8 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
   a.ksplit = pl.ksplit;
   a.ws = ws;
+  if (pl.ksplit > 1)
+    SSP_CHECK_ARG(ldout % 4 == 0 && (((uintptr_t)out) & 15) == 0, "conv: split-K output must be 16-byte aligned with ldout % 4 == 0");
   if (pl.ksplit > 1)
     SSP_CHECK_ARG(ws != nullptr && ws_floats >= (int64_t)pl.ksplit * a.M * Cout,
                   "conv: this shape runs split-K x%d and needs a workspace of %lld floats (ssp_conv_workspace_floats)",
@@ -474,7 +473,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   }
   if (rc != SSP_OK) return rc;
   if (pl.ksplit > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
                        bias, stats, a.M, Cout, pl.bm, accumulate);
     SSP_CHECK_LAUNCH("splitk_reduce");
   }

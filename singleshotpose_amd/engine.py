@@ -217,16 +217,33 @@ class Plan(object):
         self.grad_total = goff
         self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
         self.side_stream = None
+        self.dgrad_ready = None
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
         self.consumed = False
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training):
+    def forward(self, x, training, need_grad=False):
         B, H, W = self.B, self.H, self.W
         st = torch.cuda.current_stream().cuda_stream
         call = _lib.call
         call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
+        if need_grad:
+            # The flipped/transposed filters the data-gradient pass needs depend only on the current weights: repack
+            # them now on the side stream (HBM-bound copies that hide under the MFMA-bound forward convs) instead of
+            # on the critical path of backward.
+            if self.side_stream is None:
+                self.side_stream = torch.cuda.Stream(device=self.device)
+            side = self.side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            for ind in sorted(self.convs.keys(), reverse=True):
+                cs = self.convs[ind]
+                if not cs.first:
+                    call('ssp_repack_dgrad', cs.conv.weight.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin,
+                         cs.coutp, cs.k, side.cuda_stream)
+            self.dgrad_ready = side.record_event()
+        else:
+            self.dgrad_ready = None
         for op in self.ops_fwd:
             kind = op[0]
             if kind == 'conv':
@@ -312,6 +329,14 @@ class Plan(object):
         side = self.side_stream
         st2 = side.cuda_stream
         main = torch.cuda.current_stream()
+        if self.dgrad_ready is not None:
+            main.wait_event(self.dgrad_ready)       # dgrad filter repacks were queued during forward
+        else:
+            for ind in sorted(self.convs.keys(), reverse=True):   # forward ran without grad bookkeeping: repack now
+                cs = self.convs[ind]
+                if not cs.first:
+                    call('ssp_repack_dgrad', cs.conv.weight.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin,
+                         cs.coutp, cs.k, st)
         out_grads = {}
         training = self.was_training
         # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
@@ -375,9 +400,6 @@ class Plan(object):
                     with torch.cuda.stream(side):   # the all-reduce of a finished bucket is ordered after its wgrads
                         self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
                 if not cs.first:
-                    wt = cs.conv.weight
-                    call('ssp_repack_dgrad', wt.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp,
-                         cs.k, st)
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
                     call('ssp_conv_dgrad', dy_ptr, _ptr(self.dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
@@ -431,7 +453,7 @@ class _DarknetFn(torch.autograd.Function):
     def forward(ctx, plan, training, x, *params):
         ctx.plan = plan
         ctx.params = params
-        y = plan.forward(x, training)
+        y = plan.forward(x, training, need_grad=True)
         ctx.generation = plan.generation
         return y
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit: gpu tests, smoke, bench line, rocprofv3 kernel stats.  Usage: tools/gpu_check.sh [tag]
+# One GPU-box visit: gpu tests, smoke, bench line, rocprofv3 kernel stats, HBM-traffic PMC passes.  Usage: tools/gpu_check.sh [tag]
 TAG=${1:-r01}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -9,9 +9,14 @@ timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.json 2
 cat gpurun_out/bench_$TAG.json
 REPO=$(pwd)
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_$TAG.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_traffic_$TAG/$C -o p -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_traffic_$TAG/$C.log 2>&1
+done
 cd $REPO
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
-[ -n "$F" ] && cp "$F" gpurun_out/kernel_stats_$TAG.csv && head -12 "$F"
+[ -n "$F" ] && cp "$F" gpurun_out/kernel_stats_$TAG.csv && head -16 "$F" | cut -c1-150
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +8M -delete
+find gpurun_out/pmc_traffic_$TAG -name "*kernel_trace.csv" -delete
+python tools/traffic_summary.py gpurun_out/pmc_traffic_$TAG gpurun_out/traffic_$TAG.json | head -60
 tail -3 gpurun_out/smoke_$TAG.log
 tail -4 gpurun_out/pytest_$TAG.log
