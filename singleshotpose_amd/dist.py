@@ -32,10 +32,11 @@ def init_distributed(backend=None):
 class GradReducer(object):
     """Bucketed all-reduce(SUM) of the flat gradient buffer, fed by Plan.backward as layers finish."""
 
-    def __init__(self, model=None, world_size=None, bucket_bytes=48 << 20, group=None):
+    def __init__(self, model=None, world_size=None, bucket_bytes=48 << 20, group=None, force=False):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.group = group
+        self.force = force      # exercise the collective path even on one rank (tests)
         self._pending = []
         self._flat = None
         self._lo = self._hi = 0
@@ -43,11 +44,11 @@ class GradReducer(object):
         if model is not None:
             model._reducer = self
             for plan in getattr(model, '_plans', {}).values():
-                plan.reducer = self if self.world > 1 else None
+                plan.reducer = self if self.active else None
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self.force
 
     def _launch(self, lo, hi):
         if hi <= lo:

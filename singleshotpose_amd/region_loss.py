@@ -32,7 +32,9 @@ class _RegionLossFn(torch.autograd.Function):
         tgt = target.detach()
         if tgt.dtype not in (torch.float32, torch.float64):
             tgt = tgt.to(torch.float32)
-        tgt = tgt.to(out.device).contiguous().view(nB, -1)
+        if not tgt.is_cuda:
+            tgt = mod._upload(tgt.contiguous(), out.device)
+        tgt = tgt.contiguous().view(nB, -1)
         if tgt.size(1) != 50 * (2 * K + 3):
             raise ValueError("target must hold 50 x (2*num_keypoints+3) numbers per image, got %d" % tgt.size(1))
         grad = torch.empty_like(out)
@@ -80,6 +82,28 @@ class _RegionLossBase(nn.Module):
         self.pretrain_num_epochs = pretrain_num_epochs
         self.verbose = True      # print the reference's status line (one 32-byte device read per call)
         self._last_stats = None
+
+    def _upload(self, host_tensor, device):
+        """Host labels -> device without stalling the host: a `.to(device)` from pageable memory blocks the Python
+        thread until the forward pass queued before it has drained (the reference pays exactly that, train.py:83-97).
+        The labels are staged through a small ring of pinned buffers and copied asynchronously in stream order."""
+        key = (tuple(host_tensor.shape), host_tensor.dtype)
+        ring = self.__dict__.setdefault('_pin_ring', {})
+        slot = ring.get(key)
+        if slot is None:
+            slot = {'bufs': [torch.empty(host_tensor.shape, dtype=host_tensor.dtype).pin_memory() for _ in range(4)],
+                    'events': [None] * 4, 'next': 0}
+            ring[key] = slot
+        i = slot['next']
+        slot['next'] = (i + 1) % 4
+        if slot['events'][i] is not None:
+            slot['events'][i].synchronize()      # the copy that last used this buffer finished long ago
+        slot['bufs'][i].copy_(host_tensor)
+        dev = slot['bufs'][i].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        slot['events'][i] = ev
+        return dev
 
     def last_stats(self):
         """Device tensor [loss_x, loss_y, loss_conf, loss_cls, total, nGT, nCorrect, nProposals] of the last call."""
