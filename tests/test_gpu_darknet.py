@@ -208,3 +208,27 @@ def test_multi_object_train_step():
     for ind, e in enumerate(st):
         if e is not None:
             assert rel_err(model.models[ind][0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 3e-4, ind
+
+
+@pytest.mark.parametrize("size,B", [(64, 3), (224, 2), (416, 1), (288, 2)])
+def test_multiscale_training_shapes(size, B):
+    """Multi-scale training changes the input size every batch (dataset.py:66-90: 224..832 in steps of 32); each
+    shape gets its own Plan.  Tiny trunk, forward + backward against the oracle at several grids (2x2 ... 13x13)."""
+    from oracle.darknet_ref import forward_ref
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 30 + size)
+    model.train()
+    rs = np.random.RandomState(size)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, size, size)).astype(np.float32))
+    out = model(x.cuda())
+    st = clone_state(state, requires_grad=True)
+    y = forward_ref(model.blocks, st, x, training=True)
+    assert tuple(out.shape) == tuple(y.shape) == (B, 20, size // 32, size // 32)
+    assert rel_err(out.detach().cpu().numpy(), y.detach().numpy()) < TOL
+    probe = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+    (out * probe.cuda()).sum().backward()
+    (y * probe).sum().backward()
+    # bigger maps flip more max-pool / leaky decisions between two fp32 summation orders (see _check): a loose bound
+    # still catches any indexing error (those are O(1)), the strict 3e-4 bar is kept by the 96x96 tests
+    for ind, e in enumerate(st):
+        if e is not None:
+            assert rel_err(model.models[ind][0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 1e-2, ind
