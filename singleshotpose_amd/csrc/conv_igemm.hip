@@ -31,7 +31,7 @@
 // a chunk sits between two MFMA blocks.  Loads are branch-free: out-of-image taps read a clamped address and are
 // zeroed with v_cndmask; rows/columns beyond M/Cout read row 0 / the last filter and are never stored.
 template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
-__global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int LS = BK + 4;        // LDS row stride in floats (16-B aligned, conflict-free b128 reads)
   constexpr int TPR = BK / 4;       // loader threads per tile row (one float4 each)
@@ -381,7 +381,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
   pl.bm = 128;
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
   if (variant == 20 || variant == 22) { pl.bm = 64; return pl; }
-  if (variant != 0 && variant != 30 && variant != 50) return pl;   // experiment variants: plain 128x128, no split
+  if (variant != 0 && variant != 30 && variant != 50 && variant != 61 && variant != 62) return pl;   // experiment variants: plain 128x128, no split
   const int64_t t128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
   const int64_t t64 = (int64_t)ssp_cdiv(M, 64) * ssp_cdiv(Cout, 128);
   if (t128 > 1400) return pl;

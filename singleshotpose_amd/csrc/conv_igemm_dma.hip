@@ -25,14 +25,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // PASS (0 = forward, 1 = data gradient) does not change the code: it gives the two uses distinct kernel names, so a
 // profile can tell the forward launches (exclusive on the GPU) from the dgrad launches (which overlap wgrad on a
 // second stream in Plan.backward).
-template <int BM, int BN, int PASS>
-__global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
+template <int BM, int BN, int PASS, int NSLOT = 4>
+__global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
   constexpr int BK = 16, WM = 2, WN = 2, NT = 256;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int ROWB = BK * 4;                  // bytes per tile row
   constexpr int SLOTB = (BM + BN) * ROWB;       // bytes per ring slot: A rows then B rows
-  constexpr int NSLOT = 4;
   constexpr int APW = BM / 64, BPW = BN / 64;   // 1-KiB wave-instructions per wave per chunk (16 rows each)
   constexpr int LPW = APW + BPW;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are dealt to the 4 waves in groups of 16");
@@ -46,7 +45,8 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
   const int split = lid0 / ntiles, lid = lid0 - split * ntiles;
   const int tile_n = lid % p.ntile_n, tile_m = lid / p.ntile_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations stay in SGPRs
   const int wm = wid / WN, wn = wid % WN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -158,47 +158,59 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
   };
 
-  // ---- prologue: chunks 0,1,2 in flight, wait for all, publish ----
-  issue_loads(0 * SLOTB);
-  issue_loads(1 * SLOTB);
-  issue_loads(2 * SLOTB);
+  // ---- prologue: the first NSLOT-1 chunks in flight, wait for all, publish ----
+#pragma unroll
+  for (int c = 0; c < NSLOT - 1; ++c) issue_loads(c * SLOTB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // fragment registers: q = 0 fragments ping-pong between two sets (step parity) so that the NEXT chunk's first
-  // fragments can be fetched at the top of a step, a full chunk of MFMAs before they are needed
+  // fragment registers: with 4 slots the q = 0 fragments ping-pong between two sets (step parity) so that the NEXT
+  // chunk's first fragments are fetched at the top of a step, a full chunk of MFMAs before they are needed.  With 3
+  // slots (3 workgroups per CU) the next chunk is only published by this step's barrier; the third wave per SIMD
+  // covers that LDS latency instead.
   f32x4 fa0[2][TM], fb0[2][TN], fa1[TM], fb1[TN];
   read_frag(0, 0, fa0[0], fb0[0]);
 
   // one K chunk; S = ring slot of the chunk being multiplied (compile time: LDS addresses become immediates)
   auto step = [&](auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
-    constexpr int S1 = (S + 1) % NSLOT, S3 = (S + 3) % NSLOT;
-    constexpr int P = S & 1;                 // NSLOT is even: slot parity == step parity
-    issue_loads(S3 * SLOTB);                 // chunk it+3 (slot last read one barrier ago)
+    constexpr int S1 = (S + 1) % NSLOT, SL = (S + NSLOT - 1) % NSLOT;
+    constexpr int P = (NSLOT == 4) ? (S & 1) : 0;
+    issue_loads(SL * SLOTB);                 // chunk it+NSLOT-1 (slot last read one barrier ago)
     read_frag(S * SLOTB, 1, fa1, fb1);
-    read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // chunk it+1 was published by the previous barrier
+    if constexpr (NSLOT == 4) read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // published by the previous barrier
     __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads up here (the scheduler would sink them to their use)
     mma(fa0[P], fb0[P]);
     mma(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);       // ... and the wait + barrier below the MFMAs (MFMAs are register-only, so
                                              // the scheduler is otherwise free to hoist the barrier above them)
-    // chunk it+2 (issued one step ago) must have landed before it is published; this step's LPW loads stay in flight
+    // the chunk issued one step ago must have landed before it is published; this step's LPW loads stay in flight
     if constexpr (LPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (LPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (NSLOT == 3) read_frag(S1 * SLOTB, 0, fa0[0], fb0[0]);
   };
   int it = 0;
-  for (; it + 4 <= niter; it += 4) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});
+  if constexpr (NSLOT == 4) {
+    for (; it + 4 <= niter; it += 4) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+    }
+  } else {
+    for (; it + 3 <= niter; it += 3) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+    }
   }
   if (it < niter) { step(std::integral_constant<int, 0>{}); ++it; }
   if (it < niter) { step(std::integral_constant<int, 1>{}); ++it; }
-  if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
+  if constexpr (NSLOT == 4) {
+    if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
+  }
 
   // retire the run-ahead DMA before the LDS is reused by the epilogue
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -208,7 +220,7 @@ __global__ void __launch_bounds__(256) conv_igemm_dma_kernel(ConvArgs p) {
 #endif
 }
 
-template <int BM, int BN, int PASS>
+template <int BM, int BN, int PASS, int NSLOT = 4>
 static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
@@ -216,8 +228,8 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);
-  const int lds_bytes = 4 * (BM + BN) * 64;
-  auto kern = conv_igemm_dma_kernel<BM, BN, PASS>;
+  const int lds_bytes = NSLOT * (BM + BN) * 64;
+  auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT>;
   static int configured = 0;
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
@@ -234,10 +246,17 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
 // bm in {64, 128} with BN = 128, or 128 x 64 tiles for Cout <= 64.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
 int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream_t stream) {
+  // ring depth: 3 slots (48 KB, 3 workgroups per CU) for un-split 128x128 grids - the third wave per SIMD covers the
+  // barrier / LDS-latency bubbles better than the deeper prefetch does (measured +4..6 % on layers 4-8); split-K
+  // launches and the smaller tiles keep 4 slots (measured).
+  const int v = ssp_option(SSP_OPT_IGEMM_VARIANT);
+  const bool three = (v == 61) || (v != 62 && bm == 128 && a.Cout > 64 && a.ksplit == 1);
   if (is_dgrad) {
-    if (a.Cout <= 64) return launch_dma<128, 64, 1>(a, stream);
-    return bm == 64 ? launch_dma<64, 128, 1>(a, stream) : launch_dma<128, 128, 1>(a, stream);
+    if (a.Cout <= 64) return v != 62 ? launch_dma<128, 64, 1, 3>(a, stream) : launch_dma<128, 64, 1>(a, stream);
+    if (bm == 64) return v == 61 ? launch_dma<64, 128, 1, 3>(a, stream) : launch_dma<64, 128, 1>(a, stream);
+    return three ? launch_dma<128, 128, 1, 3>(a, stream) : launch_dma<128, 128, 1>(a, stream);
   }
-  if (a.Cout <= 64) return launch_dma<128, 64, 0>(a, stream);
-  return bm == 64 ? launch_dma<64, 128, 0>(a, stream) : launch_dma<128, 128, 0>(a, stream);
+  if (a.Cout <= 64) return v != 62 ? launch_dma<128, 64, 0, 3>(a, stream) : launch_dma<128, 64, 0>(a, stream);
+  if (bm == 64) return v == 61 ? launch_dma<64, 128, 0, 3>(a, stream) : launch_dma<64, 128, 0>(a, stream);
+  return three ? launch_dma<128, 128, 0, 3>(a, stream) : launch_dma<128, 128, 0>(a, stream);
 }

@@ -27,7 +27,7 @@ struct WgradArgs {
 // chunk it+2 (loaded during the previous chunk's MFMAs), are written to slot (it+2)%3 at the top of the iteration and
 // immediately refilled with chunk it+3.  Loads are branch-free (clamped address, zeroed at LDS-store time).
 template <int BMO, int BNI, int WM, int WN, int WK>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs p) {
   static_assert(WM * WN * WK == 4, "256-thread workgroups");
   constexpr int NT = 256;
   constexpr int RA = 16 * WK;  // pixel rows staged per iteration (16 per k-group of waves)

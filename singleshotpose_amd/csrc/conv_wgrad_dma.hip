@@ -26,7 +26,7 @@ struct WgradArgs {
 #define SSP_OOB 0x80000000u
 
 template <int BMO, int BNI>
-__global__ void __launch_bounds__(256) conv_wgrad_dma_kernel(WgradArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int RA = 16, WM = 2, WN = 2;
   constexpr int WTM = BMO / WM, WTN = BNI / WN, TM = WTM / 32, TN = WTN / 32;
