@@ -363,7 +363,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   return SSP_OK;
 }
 
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream_t stream);   // conv_igemm_dma.hip
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad, hipStream_t stream);   // conv_igemm_dma.hip
 
 // Tile / split selection, a pure function of the layer shape (shared by the launcher and by the host-side queries
 // that size the BN-statistics and split-K workspaces).  128x128 tiles are the workhorse.  A grid that is not a whole
@@ -371,16 +371,30 @@ int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream
 // in its last wave: the 13x13 layers (680 tiles) would run 2 waves at 66 %.  Those layers split the K loop
 // (ksplit workgroups per tile, partial tiles summed by splitk_reduce_kernel) so the grid becomes ~4 full waves;
 // mid-size grids use 64-row tiles instead.
-struct IgemmPlan { int bm, ksplit; };
+struct IgemmPlan { int bm, ksplit, slots; };   // slots: LDS ring depth of the LDS-direct kernel (0 = its default)
 static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
-  IgemmPlan pl = {256, 1};
+  IgemmPlan pl = {256, 1, 0};
   if (Cout <= 64) {
     if (Cout > 32 && Cin % 16 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50) pl.bm = 128;   // 128x64 LDS-direct tiles
     return pl;
   }
   pl.bm = 128;
+  // explicit plan (engine autotuner: "igemm_plan" = bm*100 + ksplit*10 + slots); invalid requests fall back to auto
+  const int forced = ssp_option(SSP_OPT_IGEMM_PLAN);
+  if (forced > 0) {
+    const int fbm = forced / 100, fks = (forced / 10) % 10, fsl = forced % 10;
+    const int niter16 = (Cin % 16 == 0) ? R * R * (Cin / 16) : 0;
+    const bool ok = (fbm == 64 || fbm == 128) && fks >= 1 && (fsl == 3 || fsl == 4) &&
+                    (fks == 1 || (niter16 / fks >= 8 && Cout % 4 == 0)) && Cin % 16 == 0;
+    if (ok) { pl.bm = fbm; pl.ksplit = fks; pl.slots = fsl; return pl; }
+  }
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
   if (variant == 20 || variant == 22) { pl.bm = 64; return pl; }
+  if (variant >= 70 && variant <= 75) {                      // A/B: forced split-K x(variant-68) on 128x128 tiles
+    const int niter = R * R * (Cin / 16);
+    if (Cin % 16 == 0 && Cout % 4 == 0 && niter / (variant - 68) >= 8) pl.ksplit = variant - 68;
+    return pl;
+  }
   if (variant != 0 && variant != 30 && variant != 50 && variant != 61 && variant != 62) return pl;   // experiment variants: plain 128x128, no split
   const int64_t t128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
   const int64_t t64 = (int64_t)ssp_cdiv(M, 64) * ssp_cdiv(Cout, 128);
@@ -451,7 +465,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       default: break;
     }
     if (bk >= 16 && variant != 50 && ((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
-      rc = ssp_conv_igemm_dma_launch(a, pl.bm, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
+      rc = ssp_conv_igemm_dma_launch(a, pl.bm, pl.slots, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
     } else if (pl.bm == 64) {
       rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream);
     } else if (bk == 32) {
@@ -465,7 +479,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     if (pl.bm == 128) {
       SSP_CHECK_ARG((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31),
                     "conv: image rows too long for the 32-bit tile offsets of the LDS-direct loader");
-      rc = ssp_conv_igemm_dma_launch(a, 128, prof_kind == SSP_PROF_CONV_DGRAD, stream);
+      rc = ssp_conv_igemm_dma_launch(a, 128, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);
     } else
       rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else {

@@ -245,18 +245,19 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
 
 // bm in {64, 128} with BN = 128, or 128 x 64 tiles for Cout <= 64.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int is_dgrad, hipStream_t stream) {
-  // ring depth: 3 slots (48 KB, 3 workgroups per CU) for un-split 128x128 grids - the third wave per SIMD covers the
-  // barrier / LDS-latency bubbles better than the deeper prefetch does (measured +4..6 % on layers 4-8); split-K
-  // launches and the smaller tiles keep 4 slots (measured).
-  const int v = ssp_option(SSP_OPT_IGEMM_VARIANT);
-  const bool three = (v == 61) || (v != 62 && bm == 128 && a.Cout > 64 && a.ksplit == 1);
+int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad, hipStream_t stream) {
+  // ring depth: 3 slots (48 KB, 3 workgroups per CU) for un-split 128x128 grids and the 128x64 tiles - the third wave
+  // per SIMD covers the barrier / LDS-latency bubbles better than the deeper prefetch does (measured +4..6 % on layers
+  // 2-8); split-K launches and 64x128 tiles keep 4 slots.  `slots` (3 / 4) from an explicit plan overrides this.
+  bool three = (bm == 128 && a.Cout > 64 && a.ksplit == 1) || a.Cout <= 64;
+  if (slots == 3) three = true;
+  if (slots == 4) three = false;
   if (is_dgrad) {
-    if (a.Cout <= 64) return v != 62 ? launch_dma<128, 64, 1, 3>(a, stream) : launch_dma<128, 64, 1>(a, stream);
-    if (bm == 64) return v == 61 ? launch_dma<64, 128, 1, 3>(a, stream) : launch_dma<64, 128, 1>(a, stream);
+    if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, stream) : launch_dma<128, 64, 1>(a, stream);
+    if (bm == 64) return three ? launch_dma<64, 128, 1, 3>(a, stream) : launch_dma<64, 128, 1>(a, stream);
     return three ? launch_dma<128, 128, 1, 3>(a, stream) : launch_dma<128, 128, 1>(a, stream);
   }
-  if (a.Cout <= 64) return v != 62 ? launch_dma<128, 64, 0, 3>(a, stream) : launch_dma<128, 64, 0>(a, stream);
-  if (bm == 64) return v == 61 ? launch_dma<64, 128, 0, 3>(a, stream) : launch_dma<64, 128, 0>(a, stream);
+  if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3>(a, stream) : launch_dma<128, 64, 0>(a, stream);
+  if (bm == 64) return three ? launch_dma<64, 128, 0, 3>(a, stream) : launch_dma<64, 128, 0>(a, stream);
   return three ? launch_dma<128, 128, 0, 3>(a, stream) : launch_dma<128, 128, 0>(a, stream);
 }

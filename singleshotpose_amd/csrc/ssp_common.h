@@ -53,7 +53,7 @@ struct SspProfScope {
 };
 
 // tuning knobs set through ssp_set_option (ssp_api.hip)
-enum SspOption { SSP_OPT_IGEMM_XCD = 0, SSP_OPT_IGEMM_VARIANT = 1, SSP_OPT_WGRAD_VARIANT = 2, SSP_OPT_COUNT = 3 };
+enum SspOption { SSP_OPT_IGEMM_XCD = 0, SSP_OPT_IGEMM_VARIANT = 1, SSP_OPT_WGRAD_VARIANT = 2, SSP_OPT_IGEMM_PLAN = 3, SSP_OPT_COUNT = 4 };
 int ssp_option(int which);
 
 static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -13,6 +13,8 @@ route = alias or ssp_copy_channels into a concat buffer; reorg = ssp_reorg.
 Backward mirrors it in reverse: ssp_bn_act_bwd (in place over the raw conv output) -> ssp_conv_wgrad ->
 ssp_unpack_grad, and ssp_conv_dgrad into the producer's gradient buffer (accumulating when a map has two consumers).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -131,12 +133,7 @@ class Plan(object):
                     cs.out = _Act(alloc(B * Ho * Wo * cs.coutp, **f32), 0, c, Ho, Wo, cs.coutp)
                 else:
                     cs.out = _Act(cs.raw, 0, c, cs.H, cs.W, cs.coutp)
-                cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, c, k)
-                cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, c, k)
-                cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, k)
-                cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
-                if cs.bn:
-                    cs.stats = torch.empty(cs.ntile * c * 2, **f32)
+                cs.plan_fwd = cs.plan_dgrad = 0     # explicit igemm plan codes (0 = library heuristic), see _autotune
                 # per-channel vectors: mean, invstd, scale, shift, c1, c2, dgamma, dbeta
                 cs.vec = torch.zeros(8, cs.coutp, **f32)
                 if not cs.bn:
@@ -193,6 +190,20 @@ class Plan(object):
         self.dpack = torch.empty(max(dsz, 1), **f32)
         self.gpack = torch.empty(max(wsz, 1), **f32)   # packed filter gradients (zeroed each backward)
         self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
+        if device.type == 'cuda' and os.environ.get('SSP_AUTOTUNE', '1') != '0':
+            self._autotune()
+        # statistics / split-K workspaces follow the (tuned or heuristic) plan of each launch
+        for cs in self.convs.values():
+            M = cs.M
+            _lib.call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
+            cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
+            cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
+            _lib.call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
+            cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k)
+            cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
+            if cs.bn:
+                cs.stats = torch.empty(cs.ntile * cs.cout * 2, **f32)
+        _lib.call('ssp_set_option', b'igemm_plan', 0)
         # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
         self.ws_floats = max([1] + [max(cs.ws_fwd, cs.ws_dgrad) for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
@@ -221,6 +232,63 @@ class Plan(object):
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
         self.consumed = False
+
+    # ------------------------------------------------------------------ per-shape tile / split selection
+    def _autotune(self):
+        """Times the candidate igemm plans (tile rows x split-K x LDS ring depth) of every eligible conv launch of this
+        input shape on the real buffers and keeps the fastest (per-shape tile selection).
+        The library's shape heuristic is within ~5-15 % of the best choice on some layers; which plan wins depends on
+        how the grid fills the 256 CUs.  One-off cost per (B,H,W): ~1 s for yolo-pose.cfg.  SSP_AUTOTUNE=0 disables."""
+        B = self.B
+        call = _lib.call
+        st = torch.cuda.current_stream().cuda_stream
+        f32 = dict(dtype=torch.float32, device=self.device)
+        cands = (12813, 12814, 6414, 6413, 12824, 12834)
+        elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
+        if not elig:
+            return
+        max_ws = max(3 * cs.M * max(cs.coutp, cs.cinp) for cs in elig if cs.M * max(cs.coutp, cs.cinp) <= (1 << 25)) \
+            if any(cs.M * max(cs.coutp, cs.cinp) <= (1 << 25) for cs in elig) else 1
+        ws = torch.empty(max_ws, **f32)
+        stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32)
+        gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32)
+
+        def best_of(launch, cout, mn):
+            best, best_t = 0, None
+            for code in cands:
+                if (code // 10) % 10 > 1 and mn > (1 << 25):
+                    continue
+                call('ssp_set_option', b'igemm_plan', code)
+                try:
+                    launch()
+                    ts = []
+                    for _ in range(2):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        launch()
+                        e1.record()
+                        e1.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                except _lib.SspError:
+                    continue
+                t = min(ts)
+                if best_t is None or t < best_t * 0.985:     # prefer earlier (simpler) candidates on near-ties
+                    best, best_t = code, t
+            return best
+
+        for cs in elig:
+            if cs.cout > 64:
+                cs.plan_fwd = best_of(lambda: call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(),
+                                                   None, stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp,
+                                                   cs.cout, cs.inp.ld, cs.ldraw, cs.k, 0, ws.data_ptr(), max_ws, st),
+                                      cs.cout, cs.M * cs.coutp)
+            if not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
+                cs.plan_dgrad = best_of(lambda: call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self.dpack, cs.doff),
+                                                     gscratch.data_ptr(), B, cs.H, cs.W, cs.coutp, cs.cin, cs.ldraw,
+                                                     cs.inp.ld, cs.k, 0, ws.data_ptr(), max_ws, st),
+                                        cs.cin, cs.M * cs.cinp)
+        call('ssp_set_option', b'igemm_plan', 0)
+        torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training, need_grad=False):
@@ -257,6 +325,7 @@ class Plan(object):
                     self.wversion[cs.ind] = key
                 bias = cs.conv.bias.data_ptr() if cs.conv.bias is not None else None
                 use_stats = cs.bn and training
+                call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
                 call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(), bias,
                      cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
                      cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
@@ -402,6 +471,7 @@ class Plan(object):
                 if not cs.first:
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
+                    call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
                     call('ssp_conv_dgrad', dy_ptr, _ptr(self.dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
                          cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, self.ws.data_ptr(), self.ws_floats, st)
                     written.add(src)
