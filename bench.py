@@ -114,6 +114,7 @@ def main():
     from singleshotpose_amd import _lib
     from singleshotpose_amd.darknet import Darknet
     from singleshotpose_amd.dist import GradReducer, init_distributed
+    from singleshotpose_amd.optim import SGD
     from singleshotpose_amd.region_loss import RegionLoss
 
     if world > 1:
@@ -126,8 +127,8 @@ def main():
     B, H, W = args.batch, args.size, args.size
     global_batch = B * world
     # the reference's sum-loss convention (train.py:45,388): lr / batch, decay * batch with the GLOBAL batch
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3 / global_batch, momentum=0.9, dampening=0,
-                          weight_decay=0.0005 * global_batch)
+    # torch.optim.SGD's update rule (train.py:388) as one fused launch over the flat parameter/gradient/momentum buffers
+    opt = SGD(model.parameters(), lr=1e-3 / global_batch, momentum=0.9, dampening=0, weight_decay=0.0005 * global_batch)
     reducer = GradReducer(model, world)
     x, tgt = synthetic_batch(B, H, W, 1000 + rank, device)
 

@@ -70,6 +70,14 @@ int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, 
 /* out[c] = sum_p g[p][c]  (bias gradient of the linear head conv) */
 int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream);
 
+/* ---- optimizer ------------------------------------------------------------------ */
+/* One torch.optim.SGD step (train.py:388,106) over a contiguous fp32 range of n values, in place:
+ *   d = grad + weight_decay*param;  buf = first_step ? d : momentum*buf + (1-dampening)*d;
+ *   param -= lr * (nesterov ? d + momentum*buf : buf)        (momentum == 0: param -= lr*d, momentum_buf may be NULL)
+ * All three pointers 16-byte aligned. */
+int ssp_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float dampening, float weight_decay, int nesterov, int first_step, void* stream);
+
 /* ---- layout / index kernels -------------------------------------------------------------------------------- */
 int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream);
 int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream);

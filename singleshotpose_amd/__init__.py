@@ -7,5 +7,6 @@ from . import _lib  # noqa: F401
 from .cfg import parse_cfg, print_cfg  # noqa: F401
 from .darknet import Darknet  # noqa: F401
 from .region_loss import RegionLoss, RegionLossMulti  # noqa: F401
+from . import optim  # noqa: F401
 
 __all__ = ['Darknet', 'RegionLoss', 'RegionLossMulti', 'parse_cfg', 'print_cfg']

@@ -37,6 +37,7 @@ _SIGS = {
     "ssp_bn_bwd_blocks": [],
     "ssp_bn_act_bwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P, P, P, P, P, P],
     "ssp_colsum": [P, I, L, I, P, P],
+    "ssp_sgd_step": [P, P, P, L, F, F, F, F, I, I, P],
     "ssp_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_nhwc_to_nchw": [P, P, I, I, I, I, I, P],
     "ssp_repack_fwd": [P, P, I, I, I, I, P],
@@ -57,7 +58,7 @@ _SIGS = {
 
 _RET64 = ('ssp_conv_workspace_floats',)
 
-PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region")
+PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim")
 
 
 def exported_symbols():

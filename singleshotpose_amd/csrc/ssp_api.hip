@@ -28,6 +28,8 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
                           int pool, float slope, int training, float* partial, float* dgamma, float* dbeta, float* c1,
                           float* c2, hipStream_t stream);
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
+int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float dampening,
+                        float weight_decay, int nesterov, int first_step, hipStream_t stream);
 int ssp_nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int H, int W, int Cp, int ld, hipStream_t stream);
 int ssp_nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int H, int W, int ld, hipStream_t stream);
 int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
@@ -165,6 +167,11 @@ int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, 
 int ssp_bn_bwd_blocks(void) { return ssp_bn_bwd_blocks_impl(); }
 int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream) {
   return ssp_colsum_launch(g, ldg, M, C, out, (hipStream_t)stream);
+}
+int ssp_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float dampening, float weight_decay, int nesterov, int first_step, void* stream) {
+  return ssp_sgd_step_launch(param, grad, momentum_buf, n, lr, momentum, dampening, weight_decay, nesterov, first_step,
+                             (hipStream_t)stream);
 }
 
 int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream) {

@@ -42,7 +42,8 @@ enum SspProfKind {
   SSP_PROF_BN_ACT = 3,     // BN finalize/apply/leaky/pool fwd+bwd elementwise family
   SSP_PROF_LAYOUT = 4,     // repack / transpose / reorg / maxpool
   SSP_PROF_REGION = 5,     // region loss / decode / pnp
-  SSP_PROF_NKINDS = 6
+  SSP_PROF_OPTIM = 6,      // fused SGD step
+  SSP_PROF_NKINDS = 7
 };
 
 struct SspProfScope {

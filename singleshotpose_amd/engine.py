@@ -24,6 +24,15 @@ BN_EPS = 1e-4        # darknet.py:157
 BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
 
 
+# bumped by writers that change parameter memory without going through torch ops (singleshotpose_amd.optim.SGD's
+# fused launch): part of the packed-filter cache key
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_changed():
+    _WEIGHTS_EPOCH[0] += 1
+
+
 def _ptr(t, offset=0):
     return t.data_ptr() + 4 * offset
 
@@ -319,7 +328,7 @@ class Plan(object):
                 wt = cs.conv.weight
                 # eval: repack only when the parameter changed (in-place updates bump _version; load_weights
                 # invalidates explicitly); training: weights change every step, always repack
-                key = (wt.data_ptr(), wt._version)
+                key = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
                 if training or self.wversion.get(cs.ind) != key:
                     call('ssp_repack_fwd', wt.data_ptr(), _ptr(self.wpack, cs.woff), cs.cout, cs.cin, cs.cinp, cs.k, st)
                     self.wversion[cs.ind] = key

@@ -182,3 +182,21 @@ def test_pnp_oracle_round_trip():
                 tt = t3.ravel().copy()
                 tt[d] += s
                 assert ((project(X, R3, tt, K) - uvn) ** 2).sum() >= e0 - 1e-9
+
+
+def test_fused_sgd_constructor_mirrors_torch():
+    """singleshotpose_amd.optim.SGD keeps torch.optim.SGD's constructor contract (train.py:388) - host logic only."""
+    import torch
+    from singleshotpose_amd.optim import SGD
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = SGD([p], lr=0.001 / 8, momentum=0.9, dampening=0, weight_decay=0.0005 * 8)
+    assert opt.param_groups[0]['lr'] == 0.001 / 8 and opt.param_groups[0]['weight_decay'] == 0.004
+    for grp in opt.param_groups:      # train.py:44-45
+        grp['lr'] = 0.5
+    assert opt.state_dict()['param_groups'][0]['lr'] == 0.5
+    opt.zero_grad()
+    assert opt.step() is None          # no gradients: nothing to launch, no GPU needed
+    for bad in (dict(lr=-1.0), dict(lr=0.1, momentum=-0.1), dict(lr=0.1, weight_decay=-1.0),
+                dict(lr=0.1, nesterov=True), dict(lr=0.1, momentum=0.9, dampening=0.1, nesterov=True)):
+        with pytest.raises(ValueError):
+            SGD([p], **bad)
