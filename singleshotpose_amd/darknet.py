@@ -77,7 +77,8 @@ class Darknet(nn.Module):
         self.seen = 0
         self.iter = 0
         self._plans = collections.OrderedDict()
-        self._max_plans = 3
+        self._max_plans = 32
+        self._plan_mem_frac = 0.5
 
     # ---- network construction: same module tree as darknet.py:135-249 ----
     def create_network(self, blocks):
@@ -165,12 +166,30 @@ class Darknet(nn.Module):
 
     # ---- forward: one autograd node, HIP launches only ----
     def _plan(self, x):
+        """Execution plan (buffers + per-shape kernel choices) for this input shape.  Plans are kept per shape - the
+        reference's multi-scale training (dataset.py:66-90) cycles through ~20 resolutions - least recently used
+        first out, bounded by `_max_plans` and by `_plan_mem_frac` of the device's HBM (288 GB on MI355X)."""
         key = (x.size(0), x.size(2), x.size(3), x.device.index)
         plan = self._plans.get(key)
         if plan is None:
             while len(self._plans) >= self._max_plans:
                 self._plans.popitem(last=False)
-            plan = Plan(self, x.size(0), x.size(2), x.size(3), x.device)
+            before = torch.cuda.memory_allocated(x.device)
+            while True:
+                try:
+                    plan = Plan(self, x.size(0), x.size(2), x.size(3), x.device)
+                    break
+                except torch.OutOfMemoryError:
+                    if not self._plans:
+                        raise
+                    self._plans.popitem(last=False)
+                    torch.cuda.empty_cache()
+                    before = torch.cuda.memory_allocated(x.device)
+            # forward buffers now, gradient buffers of about the same size on the first backward
+            plan.nbytes_est = 2 * max(0, torch.cuda.memory_allocated(x.device) - before)
+            budget = self._plan_mem_frac * torch.cuda.get_device_properties(x.device).total_memory
+            while self._plans and plan.nbytes_est + sum(p.nbytes_est for p in self._plans.values()) > budget:
+                self._plans.popitem(last=False)
             red = getattr(self, '_reducer', None)
             plan.reducer = red if (red is not None and red.active) else None
             self._plans[key] = plan

@@ -27,6 +27,9 @@ BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
 # bumped by writers that change parameter memory without going through torch ops (singleshotpose_amd.optim.SGD's
 # fused launch): part of the packed-filter cache key
 _WEIGHTS_EPOCH = [0]
+# autotuned igemm plan per launch shape, shared by every Plan of the process: multi-scale training (dataset.py:66-90
+# draws a new resolution every 10 batches) revisits the same ~20 shapes, each is timed once
+_TUNE_CACHE = {}
 
 
 def weights_changed():
@@ -262,7 +265,9 @@ class Plan(object):
         stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32)
         gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32)
 
-        def best_of(launch, cout, mn):
+        def best_of(launch, cout, mn, key):
+            if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
+                return _TUNE_CACHE[key]
             best, best_t = 0, None
             for code in cands:
                 if (code // 10) % 10 > 1 and mn > (1 << 25):
@@ -283,6 +288,7 @@ class Plan(object):
                 t = min(ts)
                 if best_t is None or t < best_t * 0.985:     # prefer earlier (simpler) candidates on near-ties
                     best, best_t = code, t
+            _TUNE_CACHE[key] = best
             return best
 
         for cs in elig:
@@ -290,12 +296,14 @@ class Plan(object):
                 cs.plan_fwd = best_of(lambda: call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(),
                                                    None, stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp,
                                                    cs.cout, cs.inp.ld, cs.ldraw, cs.k, 0, ws.data_ptr(), max_ws, st),
-                                      cs.cout, cs.M * cs.coutp)
+                                      cs.cout, cs.M * cs.coutp,
+                                      ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn)))
             if not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
                 cs.plan_dgrad = best_of(lambda: call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self.dpack, cs.doff),
                                                      gscratch.data_ptr(), B, cs.H, cs.W, cs.coutp, cs.cin, cs.ldraw,
                                                      cs.inp.ld, cs.k, 0, ws.data_ptr(), max_ws, st),
-                                        cs.cin, cs.M * cs.cinp)
+                                        cs.cin, cs.M * cs.cinp,
+                                        ('dgrad', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld))
         call('ssp_set_option', b'igemm_plan', 0)
         torch.cuda.synchronize()
 

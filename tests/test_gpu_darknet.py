@@ -232,3 +232,40 @@ def test_multiscale_training_shapes(size, B):
     for ind, e in enumerate(st):
         if e is not None:
             assert rel_err(model.models[ind][0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 1e-2, ind
+
+
+def test_plan_cache_multiscale_revisit_and_eviction():
+    """Multi-scale training revisits shapes (dataset.py:66-90): plans are kept per shape, the autotuned kernel choices
+    are shared process-wide (a rebuilt plan re-times nothing), and the cache is bounded by a share of device memory."""
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).cuda().eval()
+    xs = {s: torch.rand(1, 3, s, s, device='cuda') for s in (224, 256, 288)}
+    with torch.no_grad():
+        first = {s: model(x).clone() for s, x in xs.items()}
+    assert len(model._plans) == 3 and all(p.nbytes_est > 0 for p in model._plans.values())
+    tuned = dict(engine._TUNE_CACHE)
+    assert any(k[0] == 'fwd' and k[2] == 224 // 32 for k in tuned) and all(isinstance(v, int) for v in tuned.values())
+    with torch.no_grad():      # revisiting: same plan objects, same results, nothing re-timed
+        plans = dict(model._plans)
+        for s, x in xs.items():
+            assert torch.equal(model(x), first[s])
+        assert all(model._plans[k] is plans[k] for k in plans)
+    assert engine._TUNE_CACHE == tuned
+    # a second model of the same shapes re-uses the timed choices
+    other = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).cuda().eval()
+    other.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        assert torch.equal(other(xs[224]), first[224])
+    assert engine._TUNE_CACHE == tuned
+    # memory bound: with no budget only the newest plan survives
+    model._plan_mem_frac = 0.0
+    with torch.no_grad():
+        model(torch.rand(1, 3, 320, 320, device='cuda'))
+    assert list(model._plans.keys()) == [(1, 320, 320, torch.cuda.current_device())]
+    model._plan_mem_frac, model._max_plans = 0.5, 2
+    with torch.no_grad():
+        for s in (224, 256, 288):
+            model(xs[s])
+    assert [k[1] for k in model._plans] == [256, 288]
