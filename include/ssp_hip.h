@@ -81,6 +81,9 @@ int ssp_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n
 /* ---- layout / index kernels -------------------------------------------------------------------------------- */
 int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream);
 int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream);
+/* uint8 (B,H,W,C) image bytes -> fp32 [B*H*W][ld], value/255 as transforms.ToTensor (dataset.py:113-131); channels
+ * [C,Cpad) = 0.  SURVEY.md section 8(f) row 3: the byte image is uploaded instead of the fp32 NCHW tensor. */
+int ssp_u8hwc_to_nhwc(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cpad, int ld, void* stream);
 /* conv.weight (Cout,Cin,R,R) (cfg.py:157,175) -> [Cout][R*R][Cinp] */
 int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream);
 /* conv.weight -> [Cin][R*R][Coutp], taps flipped */

@@ -40,6 +40,7 @@ _SIGS = {
     "ssp_sgd_step": [P, P, P, L, F, F, F, F, I, I, P],
     "ssp_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_nhwc_to_nchw": [P, P, I, I, I, I, I, P],
+    "ssp_u8hwc_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_repack_fwd": [P, P, I, I, I, I, P],
     "ssp_repack_dgrad": [P, P, I, I, I, I, P],
     "ssp_unpack_grad": [P, P, I, I, I, I, P],

@@ -32,6 +32,8 @@ int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
 int ssp_nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int H, int W, int Cp, int ld, hipStream_t stream);
 int ssp_nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int H, int W, int ld, hipStream_t stream);
+int ssp_u8hwc_to_nhwc_launch(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cp, int ld,
+                             hipStream_t stream);
 int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
 int ssp_unpack_grad_launch(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
 int ssp_repack_dgrad_launch(const float* w, float* out, int Cout, int Cin, int Coutp, int R, hipStream_t stream);
@@ -176,6 +178,9 @@ int ssp_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n
 
 int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cpad, int ld, void* stream) {
   return ssp_nchw_to_nhwc_launch(src, dst, B, C, H, W, Cpad, ld, (hipStream_t)stream);
+}
+int ssp_u8hwc_to_nhwc(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cpad, int ld, void* stream) {
+  return ssp_u8hwc_to_nhwc_launch(src, dst, B, H, W, C, Cpad, ld, (hipStream_t)stream);
 }
 int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream) {
   return ssp_nhwc_to_nchw_launch(src, dst, B, C, H, W, ld, (hipStream_t)stream);

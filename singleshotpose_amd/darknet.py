@@ -165,29 +165,29 @@ class Darknet(nn.Module):
         return models
 
     # ---- forward: one autograd node, HIP launches only ----
-    def _plan(self, x):
+    def _plan(self, shape, device):
         """Execution plan (buffers + per-shape kernel choices) for this input shape.  Plans are kept per shape - the
         reference's multi-scale training (dataset.py:66-90) cycles through ~20 resolutions - least recently used
         first out, bounded by `_max_plans` and by `_plan_mem_frac` of the device's HBM (288 GB on MI355X)."""
-        key = (x.size(0), x.size(2), x.size(3), x.device.index)
+        key = (shape[0], shape[1], shape[2], device.index)
         plan = self._plans.get(key)
         if plan is None:
             while len(self._plans) >= self._max_plans:
                 self._plans.popitem(last=False)
-            before = torch.cuda.memory_allocated(x.device)
+            before = torch.cuda.memory_allocated(device)
             while True:
                 try:
-                    plan = Plan(self, x.size(0), x.size(2), x.size(3), x.device)
+                    plan = Plan(self, shape[0], shape[1], shape[2], device)
                     break
                 except torch.OutOfMemoryError:
                     if not self._plans:
                         raise
                     self._plans.popitem(last=False)
                     torch.cuda.empty_cache()
-                    before = torch.cuda.memory_allocated(x.device)
+                    before = torch.cuda.memory_allocated(device)
             # forward buffers now, gradient buffers of about the same size on the first backward
-            plan.nbytes_est = 2 * max(0, torch.cuda.memory_allocated(x.device) - before)
-            budget = self._plan_mem_frac * torch.cuda.get_device_properties(x.device).total_memory
+            plan.nbytes_est = 2 * max(0, torch.cuda.memory_allocated(device) - before)
+            budget = self._plan_mem_frac * torch.cuda.get_device_properties(device).total_memory
             while self._plans and plan.nbytes_est + sum(p.nbytes_est for p in self._plans.values()) > budget:
                 self._plans.popitem(last=False)
             red = getattr(self, '_reducer', None)
@@ -212,14 +212,23 @@ class Darknet(nn.Module):
                                "(no CPU fallback exists; the reference's PyTorch-CPU path lives under oracle/ as a "
                                "test checker)" % x.device)
         _lib.load()
-        if x.dim() != 4 or x.size(1) != int(self.blocks[0].get('channels', 3)):
-            raise ValueError("expected a (B,%s,H,W) input" % self.blocks[0].get('channels', 3))
-        x = x.detach().to(torch.float32).contiguous()
+        nc = int(self.blocks[0].get('channels', 3))
+        if x.dtype == torch.uint8:
+            # image bytes as the decoder yields them, (B,H,W,C): ToTensor's /255 and the NHWC layout happen on the GPU
+            if x.dim() != 4 or x.size(3) != nc:
+                raise ValueError("expected a (B,H,W,%d) uint8 input" % nc)
+            x = x.detach().contiguous()
+            shape = (x.size(0), x.size(1), x.size(2))
+        else:
+            if x.dim() != 4 or x.size(1) != nc:
+                raise ValueError("expected a (B,%d,H,W) input" % nc)
+            x = x.detach().to(torch.float32).contiguous()
+            shape = (x.size(0), x.size(2), x.size(3))
         params = self._params()
         for p in params:
             if p.device != x.device:
                 raise RuntimeError("model parameters are on %s but the input is on %s - call model.cuda()" % (p.device, x.device))
-        plan = self._plan(x)
+        plan = self._plan(shape, x.device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad:
             return _DarknetFn.apply(plan, self.training, x, *params)

@@ -312,7 +312,10 @@ class Plan(object):
         B, H, W = self.B, self.H, self.W
         st = torch.cuda.current_stream().cuda_stream
         call = _lib.call
-        call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
+        if x.dtype == torch.uint8:     # (B,H,W,C) image bytes: ToTensor's /255 and the NHWC padding in one pass
+            call('ssp_u8hwc_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, H, W, self.in_c, self.in_cp, self.in_cp, st)
+        else:
+            call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
         if need_grad:
             # The flipped/transposed filters the data-gradient pass needs depend only on the current weights: repack
             # them now on the side stream (HBM-bound copies that hide under the MFMA-bound forward convs) instead of

@@ -269,3 +269,27 @@ def test_plan_cache_multiscale_revisit_and_eviction():
         for s in (224, 256, 288):
             model(xs[s])
     assert [k[1] for k in model._plans] == [256, 288]
+
+
+def test_uint8_image_input_equals_totensor_path():
+    """Darknet accepts the decoder's uint8 (B,H,W,3) bytes directly: same output, bit for bit, as feeding the
+    ToTensor'd NCHW float tensor the reference's loader builds (dataset.py:113-131); training step included."""
+    model, _ = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 77)
+    rs = np.random.RandomState(5)
+    img = torch.from_numpy(rs.randint(0, 256, (3, 96, 96, 3)).astype(np.uint8))
+    x_float = img.permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous()
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(img.cuda()), model(x_float.cuda()))
+    model.train()
+    outs, grads = [], []
+    for inp in (img.cuda(), x_float.cuda()):
+        model.zero_grad()
+        y = model(inp)
+        y.square().sum().backward()
+        outs.append(y.detach().clone())
+        grads.append(model.models[0][0].weight.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(grads[0].cpu().numpy(), grads[1].cpu().numpy()) < 1e-5      # wgrad sums with fp32 atomics
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 96, 96, dtype=torch.uint8, device='cuda'))

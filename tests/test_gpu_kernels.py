@@ -276,3 +276,22 @@ def test_error_reporting():
     G, _lib = _imports()
     with pytest.raises(_lib.SspError, match="1x1 and 3x3"):
         _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, None, 0, G.stream())
+
+
+@pytest.mark.parametrize("B,H,W,C,Cp,ld", [(2, 32, 32, 3, 4, 4), (1, 5, 7, 3, 4, 4), (1, 3, 3, 1, 4, 8), (2, 4, 6, 4, 4, 4),
+                                          (1, 1, 1, 3, 4, 4)])
+def test_u8_image_to_nhwc_bit_exact(B, H, W, C, Cp, ld):
+    """uint8 HWC bytes -> fp32 NHWC/255: bit-exact against ToTensor's arithmetic (uint8 -> float32, true division by
+    255; dataset.py:113-131 via torchvision.transforms.ToTensor), every byte value covered."""
+    from singleshotpose_amd import _lib
+    rs = np.random.RandomState(B * 1000 + H)
+    img = rs.randint(0, 256, (B, H, W, C)).astype(np.uint8)
+    img.reshape(-1)[:min(256, img.size)] = np.arange(min(256, img.size), dtype=np.uint8)
+    src = torch.from_numpy(img).cuda()
+    dst = torch.full((B * H * W, ld), -7.0, device='cuda')
+    _lib.call('ssp_u8hwc_to_nhwc', src.data_ptr(), dst.data_ptr(), B, H, W, C, Cp, ld,
+              torch.cuda.current_stream().cuda_stream)
+    want = torch.from_numpy(img).to(torch.float32).div(255).numpy().reshape(-1, C)       # ToTensor: .float().div(255)
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[:, :C], want)
+    assert np.all(got[:, C:Cp] == 0.0) and np.all(got[:, Cp:] == -7.0)
