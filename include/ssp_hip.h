@@ -121,6 +121,16 @@ int ssp_region_decode_all(const float* out, float* rows, int nB, int nA, int nC,
 int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, double* Rt, int n, int N, int max_iter,
                     void* stream);
 
+/* ---- evaluation metrics (valid.py:148-172, utils.py:31-58) ------------------------ */
+/* n pose pairs over one mesh: vertices [N][3], Rt_gt / Rt_pr [n][12] = R (9, row-major) | t (3) (ssp_pnp_batched's
+ * layout), K [9] (k_per_pose = 0) or [n][9], all doubles on the device ->
+ * out [n][4] = {mean 2D reprojection distance (float32 projections, valid.py:160-165), mean 3D vertex distance
+ * (valid.py:168-172), translation distance (valid.py:148), angular distance in degrees (utils.py:31-35)} */
+int ssp_pose_errors(const double* vertices, int N, const double* Rt_gt, const double* Rt_pr, const double* K,
+                    int k_per_pose, int n, double* out, void* stream);
+/* calc_pts_diameter (utils.py:50-58): out[0] = largest pairwise distance of pts [N][3]; scratch: 8 bytes */
+int ssp_pts_diameter(const double* pts, int N, double* out, double* scratch, void* stream);
+
 /* ---- timed-launch bookkeeping (bench.py roofline): HIP events around every launch of a kernel family -------- */
 int ssp_prof_enable(int on);
 /* ms[k], work[k] (FLOPs or bytes), count[k] for k in 0..ssp_prof_nkinds()-1; synchronises on the recorded events */

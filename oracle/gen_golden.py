@@ -223,5 +223,37 @@ def main():
     run_net(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 2, 416, 416, 7, True, 'full_train')
 
 
+def gen_eval():
+    """Evaluation maths golden vectors from the reference's own utils.py functions and valid.py:146-172 expressions."""
+    ref_utils, _, _ = import_reference()
+    from oracle.eval_ref import synthetic_eval_case
+    rec = {}
+    for seed in (0, 1):
+        pts, K, R_gt, t_gt, R_pr, t_pr = synthetic_eval_case(seed, n_pose=6, n_vert=700 if seed == 0 else 257)
+        vertices = np.concatenate((pts.T, np.ones((1, pts.shape[0]))), axis=0)
+        rows = []
+        for i in range(R_gt.shape[0]):
+            trans_dist = np.sqrt(np.sum(np.square(t_gt[i] - t_pr[i])))
+            with np.errstate(invalid='ignore'):
+                angle_dist = ref_utils.calcAngularDistance(R_gt[i], R_pr[i])
+            Rt_gt = np.concatenate((R_gt[i], t_gt[i]), axis=1)
+            Rt_pr = np.concatenate((R_pr[i], t_pr[i]), axis=1)
+            proj_gt = ref_utils.compute_projection(vertices, Rt_gt, K)
+            proj_pr = ref_utils.compute_projection(vertices, Rt_pr, K)
+            pixel_dist = np.mean(np.linalg.norm(proj_gt - proj_pr, axis=0))
+            v_gt = ref_utils.compute_transformation(vertices, Rt_gt)
+            v_pr = ref_utils.compute_transformation(vertices, Rt_pr)
+            vertex_dist = np.mean(np.linalg.norm(v_gt - v_pr, axis=0))
+            rows.append([pixel_dist, vertex_dist, trans_dist, angle_dist])
+        rec['errors_%d' % seed] = np.array(rows, dtype=np.float64)
+        rec['diameter_%d' % seed] = np.array([ref_utils.calc_pts_diameter(pts)], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, 'eval_metrics.npz'), **rec)
+    print('eval_metrics', rec['errors_0'][:2], rec['diameter_0'])
+
+
 if __name__ == '__main__':
-    main()
+    if '--eval' in sys.argv:
+        gen_eval()
+    else:
+        main()
+        gen_eval()

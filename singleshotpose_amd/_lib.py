@@ -37,6 +37,8 @@ _SIGS = {
     "ssp_bn_bwd_blocks": [],
     "ssp_bn_act_bwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P, P, P, P, P, P],
     "ssp_colsum": [P, I, L, I, P, P],
+    "ssp_pose_errors": [P, I, P, P, P, I, I, P, P],
+    "ssp_pts_diameter": [P, I, P, P, P],
     "ssp_sgd_step": [P, P, P, L, F, F, F, F, I, I, P],
     "ssp_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_nhwc_to_nchw": [P, P, I, I, I, I, I, P],

@@ -32,6 +32,9 @@ int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
 int ssp_nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int H, int W, int Cp, int ld, hipStream_t stream);
 int ssp_nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int H, int W, int ld, hipStream_t stream);
+int ssp_pose_errors_launch(const double* verts, int N, const double* Rt_gt, const double* Rt_pr, const double* K,
+                           int k_per_pose, int n, double* out, hipStream_t stream);
+int ssp_pts_diameter_launch(const double* pts, int N, double* out, double* scratch, hipStream_t stream);
 int ssp_u8hwc_to_nhwc_launch(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cp, int ld,
                              hipStream_t stream);
 int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
@@ -237,6 +240,13 @@ int ssp_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
   return SSP_OK;
+}
+int ssp_pose_errors(const double* vertices, int N, const double* Rt_gt, const double* Rt_pr, const double* K,
+                    int k_per_pose, int n, double* out, void* stream) {
+  return ssp_pose_errors_launch(vertices, N, Rt_gt, Rt_pr, K, k_per_pose, n, out, (hipStream_t)stream);
+}
+int ssp_pts_diameter(const double* pts, int N, double* out, double* scratch, void* stream) {
+  return ssp_pts_diameter_launch(pts, N, out, scratch, (hipStream_t)stream);
 }
 int ssp_prof_nkinds(void) { return SSP_PROF_NKINDS; }
 int ssp_prof_collect(double* ms, double* work, int64_t* count) {

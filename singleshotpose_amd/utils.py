@@ -110,6 +110,53 @@ def pnp_batched(points_3D, points_2D, cameraMatrix, max_iter=20):
     return Rt[:, :9].reshape(n, 3, 3).copy(), Rt[:, 9:].reshape(n, 3, 1).copy()
 
 
+def _to_dev_f64(a):
+    if not torch.cuda.is_available():
+        raise RuntimeError("the batched evaluation maths runs on the MI355X HIP kernels only (no CPU fallback)")
+    t = a if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))
+    return t.to(device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float64).contiguous()
+
+
+def pose_errors_batched(vertices, R_gt, t_gt, R_pr, t_pr, internal_calibration):
+    """valid.py:146-172 for n pose pairs in one launch.
+
+    vertices (4,N) homogeneous or (3,N) (the mesh valid.py:60-61 loads), R_* (n,3,3), t_* (n,3,1) or (n,3),
+    K (3,3) or (n,3,3) - numpy arrays or tensors (device tensors, e.g. straight from the PnP kernel, are used in
+    place) -> float64 ndarray (n,4): [pixel_dist (errs_2d), vertex_dist (errs_3d), trans_dist, angle_dist in degrees].
+    """
+    v = _to_dev_f64(vertices)
+    if v.dim() != 2 or v.size(0) not in (3, 4):
+        raise ValueError("vertices must be (3,N) or (4,N)")
+    v = v[:3].t().contiguous()
+    Rg, Rp = _to_dev_f64(R_gt).reshape(-1, 9), _to_dev_f64(R_pr).reshape(-1, 9)
+    tg, tp = _to_dev_f64(t_gt).reshape(-1, 3), _to_dev_f64(t_pr).reshape(-1, 3)
+    n = Rg.size(0)
+    if not (Rp.size(0) == tg.size(0) == tp.size(0) == n):
+        raise ValueError("R_gt, t_gt, R_pr, t_pr must hold the same number of poses")
+    K = _to_dev_f64(internal_calibration).reshape(-1, 9)
+    if K.size(0) not in (1, n):
+        raise ValueError("internal_calibration must be (3,3) or (n,3,3)")
+    Rt_gt = torch.cat((Rg, tg), dim=1).contiguous()
+    Rt_pr = torch.cat((Rp, tp), dim=1).contiguous()
+    out = torch.empty(n, 4, dtype=torch.float64, device=v.device)
+    _lib.call('ssp_pose_errors', v.data_ptr(), v.size(0), Rt_gt.data_ptr(), Rt_pr.data_ptr(), K.data_ptr(),
+              1 if (K.size(0) == n and n > 1) else 0, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return out.cpu().numpy()
+
+
+def calc_pts_diameter_gpu(pts):
+    """calc_pts_diameter (utils.py:50-58) on the device: exact fp64 maximum over all N(N+1)/2 pairs, one launch
+    instead of the reference's N numpy passes (minutes for a 6 k vertex mesh)."""
+    p = _to_dev_f64(pts)
+    if p.dim() != 2 or p.size(1) != 3:
+        raise ValueError("pts must be (N,3)")
+    out = torch.empty(1, dtype=torch.float64, device=p.device)
+    scratch = torch.empty(1, dtype=torch.float64, device=p.device)
+    _lib.call('ssp_pts_diameter', p.data_ptr(), p.size(0), out.data_ptr(), scratch.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return float(out.item())
+
+
 def pnp(points_3D, points_2D, cameraMatrix):
     """(N,3) object points, (N,2) image points, (3,3) K -> R (3,3), t (3,1) float64 (utils.py:86-100)."""
     assert points_3D.shape[0] == points_2D.shape[0], 'points 3D and points 2D must have same number of vertices'

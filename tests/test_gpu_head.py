@@ -163,3 +163,60 @@ def test_pnp_round_trip_and_oracle():
     R1, t1 = pnp(X.astype(np.float32), uvs[0].astype(np.float32), K.astype(np.float32))
     assert R1.shape == (3, 3) and t1.shape == (3, 1) and R1.dtype == np.float64
     assert np.abs(project(X, R1, t1, K) - uvs[0]).max() < 1e-2
+
+
+def test_pose_errors_and_diameter_vs_reference_golden():
+    """ssp_pose_errors / ssp_pts_diameter against the reference's own numbers (tests/golden/eval_metrics.npz from
+    utils.py:31-58 + valid.py:146-172) and the oracle: diameter bit-exact (a max of exactly rounded fp64 terms),
+    float64 means to 1e-12, the float32-projection mean to 1e-5 relative (the reference sums it in float32)."""
+    from oracle.eval_ref import pose_errors_ref, pts_diameter_ref, synthetic_eval_case
+    from singleshotpose_amd import utils as U
+    g = gold('eval_metrics.npz')
+    for seed, nv in ((0, 700), (1, 257)):
+        pts, K, R_gt, t_gt, R_pr, t_pr = synthetic_eval_case(seed, n_pose=6, n_vert=nv)
+        vertices = np.concatenate((pts.T, np.ones((1, nv))), axis=0)
+        got = U.pose_errors_batched(vertices, R_gt, t_gt, R_pr, t_pr, K)
+        want = g['errors_%d' % seed]
+        assert got.shape == want.shape == (6, 4)
+        assert np.allclose(got[:, 0], want[:, 0], rtol=1e-5, atol=1e-6)
+        assert np.allclose(got[:, 1:3], want[:, 1:3], rtol=1e-12, atol=1e-15)
+        assert np.allclose(got[1:, 3], want[1:, 3], rtol=1e-9)
+        assert got[0, 3] < 1e-5 or np.isnan(got[0, 3])        # identical rotations: acos argument rounds to ~1
+        assert U.calc_pts_diameter_gpu(pts) == float(g['diameter_%d' % seed][0])
+        # (3,N) vertices and per-pose intrinsics take the same path
+        got2 = U.pose_errors_batched(pts.T, R_gt, t_gt.reshape(6, 3), R_pr, t_pr, np.broadcast_to(K, (6, 3, 3)))
+        assert np.array_equal(got2[:, :3], got[:, :3])
+    # other sizes against the oracle: single point, non-multiple-of-256 counts, one pose
+    for seed, nv, npose in ((3, 1, 1), (4, 255, 2), (5, 1031, 3)):
+        pts, K, R_gt, t_gt, R_pr, t_pr = synthetic_eval_case(seed, n_pose=npose, n_vert=nv)
+        vertices = np.concatenate((pts.T, np.ones((1, nv))), axis=0)
+        got = U.pose_errors_batched(vertices, R_gt, t_gt, R_pr, t_pr, K)
+        want = np.array([pose_errors_ref(vertices, R_gt[i], t_gt[i], R_pr[i], t_pr[i], K) for i in range(npose)])
+        assert np.allclose(got[:, :3], want[:, :3], rtol=1e-5, atol=1e-9)
+        assert U.calc_pts_diameter_gpu(pts) == pts_diameter_ref(pts)
+    with pytest.raises(ValueError):
+        U.pose_errors_batched(np.zeros((2, 5)), R_gt, t_gt, R_pr, t_pr, K)
+
+
+def test_validation_chain_decode_pnp_errors_on_device():
+    """valid.py:100-177 as three launches: decode -> batched PnP (gt and predicted corners) -> batched pose errors."""
+    from oracle.eval_ref import synthetic_eval_case
+    from singleshotpose_amd import utils as U
+    pts, K, R_gt, t_gt, _, _ = synthetic_eval_case(11, n_pose=5, n_vert=400)
+    vertices = np.concatenate((pts.T, np.ones((1, 400))), axis=0)
+    corners3D = U.get_3D_corners(vertices)
+    obj = np.concatenate((np.zeros((3, 1)), corners3D[:3, :]), axis=1).T          # valid.py:152: centroid + 8 corners
+    rs = np.random.RandomState(2)
+    img_gt, img_pr = [], []
+    for i in range(5):
+        cam = K.dot(np.concatenate((R_gt[i], t_gt[i]), axis=1)).dot(np.concatenate((obj.T, np.ones((1, 9)))))
+        uv = (cam[:2] / cam[2]).T
+        img_gt.append(uv)
+        img_pr.append(uv + rs.standard_normal(uv.shape) * 0.5)           # half-pixel corner noise
+    objs = np.broadcast_to(obj, (5, 9, 3))
+    Rg, tg = U.pnp_batched(objs, np.stack(img_gt), K)
+    Rp, tp = U.pnp_batched(objs, np.stack(img_pr), K)
+    err = U.pose_errors_batched(vertices, Rg, tg, Rp, tp, K)
+    assert np.allclose(Rg, R_gt, atol=1e-6) and np.allclose(tg, t_gt, atol=1e-6)
+    assert np.all(err[:, 0] < 3.0) and np.all(err[:, 0] > 0.0)           # reprojection error of the order of the noise
+    assert np.all(err[:, 1] < 0.02) and np.all(err[:, 3] < 5.0)

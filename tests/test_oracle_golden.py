@@ -122,3 +122,15 @@ def test_darknet_full_eval_matches_reference(root_dir):
 
 def test_darknet_full_train_matches_reference(root_dir):
     _check_net(os.path.join(root_dir, 'cfg', 'yolo-pose.cfg'), 'full_train', 2, 416, 416, 7, True)
+
+
+def test_eval_metrics_oracle_vs_reference_golden():
+    """oracle.eval_ref against the reference's own utils.py / valid.py:146-172 results (tests/golden/eval_metrics.npz)."""
+    from oracle.eval_ref import pose_errors_ref, pts_diameter_ref, synthetic_eval_case
+    g = np.load(os.path.join(GOLD, 'eval_metrics.npz'))
+    for seed, nv in ((0, 700), (1, 257)):
+        pts, K, R_gt, t_gt, R_pr, t_pr = synthetic_eval_case(seed, n_pose=6, n_vert=nv)
+        vertices = np.concatenate((pts.T, np.ones((1, nv))), axis=0)
+        got = np.array([pose_errors_ref(vertices, R_gt[i], t_gt[i], R_pr[i], t_pr[i], K) for i in range(6)])
+        assert np.array_equal(got, g['errors_%d' % seed])
+        assert pts_diameter_ref(pts) == float(g['diameter_%d' % seed][0])
