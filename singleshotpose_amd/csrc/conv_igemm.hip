@@ -482,6 +482,8 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       rc = ssp_conv_igemm_dma_launch(a, 128, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);
     } else
       rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
+  } else if (bk >= 16 && variant != 50 && ((int64_t)(256 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
+    rc = ssp_conv_igemm_dma_launch(a, 256, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);   // 256x32 LDS-direct tiles
   } else {
     rc = (bk >= 16) ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }

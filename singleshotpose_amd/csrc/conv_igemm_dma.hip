@@ -25,16 +25,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // PASS (0 = forward, 1 = data gradient) does not change the code: it gives the two uses distinct kernel names, so a
 // profile can tell the forward launches (exclusive on the GPU) from the dgrad launches (which overlap wgrad on a
 // second stream in Plan.backward).
-template <int BM, int BN, int PASS, int NSLOT = 4>
+//
+// WM x WN = arrangement of the 4 waves over the tile: 2 x 2 for the square tiles, 4 x 1 for the 256 x 32 tile that
+// serves GEMMs with 32 output columns (the data gradient of layer 2: 64 -> 32 channels at 208 x 208).
+template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
 __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
-  constexpr int BK = 16, WM = 2, WN = 2, NT = 256;
+  constexpr int BK = 16, NT = 256;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int ROWB = BK * 4;                  // bytes per tile row
   constexpr int SLOTB = (BM + BN) * ROWB;       // bytes per ring slot: A rows then B rows
-  constexpr int APW = BM / 64, BPW = BN / 64;   // 1-KiB wave-instructions per wave per chunk (16 rows each)
+  constexpr int APW = BM / 64, BPW = (BN + 63) / 64;   // 1-KiB wave-instructions per wave per chunk (16 rows each)
   constexpr int LPW = APW + BPW;
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile rows are dealt to the 4 waves in groups of 16");
+  // a B tile narrower than 64 rows has fewer 1-KiB pieces than waves: the spare waves still issue their (all
+  // out-of-range, zero-filled) load so that every wave's vmcnt bookkeeping is identical; it lands in a scratch KiB
+  // behind the ring
+  constexpr bool B_SPARE = (BN % 64) != 0;
+  static_assert(BM % 64 == 0 && BN % 32 == 0, "tile rows are dealt to the 4 waves in groups of 16");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];   // NSLOT * SLOTB bytes
   char* const lds = reinterpret_cast<char*>(smem);
@@ -86,8 +94,10 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   for (int j = 0; j < BPW; ++j) {
     const int row = (wid + 4 * j) * 16 + lrow;
     const int chunk = lch ^ ((row >> 2) & 3);
-    b_voff[j] = (n0 + row < p.Cout) ? (unsigned)(row * K + chunk * 4) * 4u : SSP_OOB;
+    b_voff[j] = (row < BN && n0 + row < p.Cout) ? (unsigned)(row * K + chunk * 4) * 4u : SSP_OOB;
   }
+  // LDS byte offset (inside a slot) of this wave's B pieces; spare waves point at the scratch KiB (slot-independent)
+  const bool b_spare = B_SPARE && (wid * 16 >= BN);
 
   // ---- K-chunk walker (scalar): tap (dy,dx), channel offset, filter column; lane offsets recomputed per tap ----
   int ld_tap = it_begin / cpt;
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
                                                16, a_voff[j], ld_c0 * 4, 0, 0);
 #pragma unroll
     for (int j = 0; j < BPW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds + slot_bytes + BM * ROWB + (wid + 4 * j) * 1024),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds + (b_spare ? NSLOT * SLOTB : slot_bytes + BM * ROWB + (wid + 4 * j) * 1024)),
                                                16, b_voff[j], ld_koff * 4, 0, 0);
     // advance; past the last chunk the filter column is clamped and the tap index runs out of range (all lanes OOB)
     ld_koff = min(ld_koff + BK, K - BK);
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
 #endif
 }
 
-template <int BM, int BN, int PASS, int NSLOT = 4>
+template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
 static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
@@ -228,8 +238,8 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);
-  const int lds_bytes = NSLOT * (BM + BN) * 64;
-  auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT>;
+  const int lds_bytes = NSLOT * (BM + BN) * 64 + ((BN % 64) ? 1024 : 0);
+  auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT, WM, WN>;
   static int configured = 0;
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
@@ -243,7 +253,7 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   return SSP_OK;
 }
 
-// bm in {64, 128} with BN = 128, or 128 x 64 tiles for Cout <= 64.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
+// bm in {64, 128} with BN = 128, 128 x 64 tiles for Cout <= 64, 256 x 32 tiles for Cout <= 32.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
 int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad, hipStream_t stream) {
   // ring depth: 3 slots (48 KB, 3 workgroups per CU) for un-split 128x128 grids and the 128x64 tiles - the third wave
@@ -252,6 +262,7 @@ int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad
   bool three = (bm == 128 && a.Cout > 64 && a.ksplit == 1) || a.Cout <= 64;
   if (slots == 3) three = true;
   if (slots == 4) three = false;
+  if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, stream);
   if (is_dgrad) {
     if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, stream) : launch_dma<128, 64, 1>(a, stream);
     if (bm == 64) return three ? launch_dma<64, 128, 1, 3>(a, stream) : launch_dma<64, 128, 1>(a, stream);

@@ -21,6 +21,7 @@ struct WgradArgs {
   float* dw;
   int H, W, Cin, Cout, lddy, ldx, R, M;
   int ntile_co, ntile_ci, nsplit, chunk_m;
+  int fold;   // filter taps per cin tile: 1, or BNI / Cin when Cin < BNI (thin layers: two taps of 32 cins share a tile)
 };
 
 #define SSP_OOB 0x80000000u
@@ -39,14 +40,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   char* const lds = reinterpret_cast<char*>(smem);
 
   const int taps = p.R * p.R;
+  const int tap_groups = (taps + p.fold - 1) / p.fold;
   int bid = blockIdx.x;
   const int split = bid % p.nsplit; bid /= p.nsplit;
-  const int tap = bid % taps; bid /= taps;
+  const int tap = (bid % tap_groups) * p.fold; bid /= tap_groups;   // first tap of this workgroup's tile
   const int tile_ci = bid % p.ntile_ci;
   const int tile_co = bid / p.ntile_ci;
   const int co0 = tile_co * BMO, ci0 = tile_ci * BNI;
   const int pad = p.R >> 1;
-  const int dy = tap / p.R - pad, dx = tap % p.R - pad;
 
   const int m_begin = split * p.chunk_m;
   const int m_end = min(p.M, m_begin + p.chunk_m);
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 
   // ---- loader lanes: piece g (1 KiB) of a tile = bytes [g*1024, g*1024+1024) of the row-major [16][C] image ----
   unsigned a_voff[APW], b_off[BPW];
-  int b_row[BPW], b_x[BPW], b_y[BPW];
+  int b_row[BPW], b_x[BPW], b_y[BPW], b_dx[BPW], b_dy[BPW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int byte = (wid + 4 * j) * 1024 + lane * 16;
@@ -71,7 +72,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     const int byte = (wid + 4 * j) * 1024 + lane * 16;
     const int row = byte / (BNI * 4), col = (byte % (BNI * 4)) / 4;
     b_row[j] = row;
-    b_off[j] = (ci0 + col < p.Cin) ? (unsigned)((row * p.ldx + ci0 + col) * 4) : SSP_OOB;
+    // tile column -> (tap, cin): with fold > 1 the tile spans `fold` consecutive taps of all Cin channels; the tap's
+    // pixel shift goes into the lane offset (relative to the pixel-row base of the descriptor)
+    const int tl = (p.fold > 1) ? tap + col / p.Cin : tap;
+    const int cc = (p.fold > 1) ? col % p.Cin : ci0 + col;
+    b_dy[j] = tl / p.R - pad;
+    b_dx[j] = tl % p.R - pad;
+    b_off[j] = (cc < p.Cin && tl < taps) ? (unsigned)(((row + b_dy[j] * p.W + b_dx[j] + p.W + 1) * p.ldx + cc) * 4) : SSP_OOB;
     const int m = m_begin + row;
     b_x[j] = m % p.W;
     b_y[j] = (m / p.W) % p.H;
@@ -84,14 +91,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.dy + abase), 0, left > 0 ? (int)min((int64_t)left * p.lddy * 4, (int64_t)0x7fffffff) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + ((int64_t)ld_m + dy * p.W + dx) * p.ldx), 0, (int)SSP_OOB, 0x00020000);
+        (void*)(p.x + ((int64_t)ld_m - p.W - 1) * p.ldx), 0, (int)SSP_OOB, 0x00020000);   // base = pixel (y-1, x-1)
 #pragma unroll
     for (int j = 0; j < APW; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds + slot_bytes + (wid + 4 * j) * 1024),
                                                16, a_voff[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
-      const int yy = b_y[j] + dy, xx = b_x[j] + dx;
+      const int yy = b_y[j] + b_dy[j], xx = b_x[j] + b_dx[j];
       const bool ok = (b_row[j] < left) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds + slot_bytes + ABYTES + (wid + 4 * j) * 1024),
                                                16, ok ? b_off[j] : SSP_OOB, 0, 0, 0);
@@ -197,11 +204,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int ci = ci0 + wn * WTN + j * 32 + li;
+      const int col = wn * WTN + j * 32 + li;
+      const int tl = (p.fold > 1) ? tap + col / p.Cin : tap;
+      const int ci = (p.fold > 1) ? col % p.Cin : ci0 + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((int64_t)co * taps + tap) * p.Cin + ci, acc[i][j][r]);
+        if (co < p.Cout && ci < p.Cin && tl < taps) atomicAdd(p.dw + ((int64_t)co * taps + tl) * p.Cin + ci, acc[i][j][r]);
       }
     }
 #endif
@@ -212,7 +221,8 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   constexpr int RA = 16;
   a.ntile_co = ssp_cdiv(a.Cout, BMO);
   a.ntile_ci = ssp_cdiv(a.Cin, BNI);
-  const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * a.R * a.R;
+  a.fold = (a.Cin < BNI && BNI % a.Cin == 0 && a.R > 1) ? BNI / a.Cin : 1;
+  const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold);
   const int lds_bytes = NSLOT * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT>;
   static int configured = 0;
@@ -255,11 +265,11 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
 // returns 1 when the shape is handled here (launched), 0 when the caller should use conv_wgrad.hip, < 0 on error
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                            int ldx, int R, hipStream_t stream) {
-  if (Cout < 64 || Cin < 64) return 0;
+  if (Cout < 64 || (Cin < 64 && !(Cin == 32 && R == 3))) return 0;   // Cin 32: two taps fold into one 64-column tile
   if (W < 8) return 0;   // the per-lane pixel walker advances 16 pixels with at most two row wraps
   const int64_t M = (int64_t)B * H * W;
   // 32-bit lane offsets: 16 staged rows of the widest operand, and the whole dY range of a workgroup
-  if ((int64_t)16 * lddy * 4 >= (1ll << 31) || (int64_t)16 * ldx * 4 >= (1ll << 31)) return 0;
+  if ((int64_t)16 * lddy * 4 >= (1ll << 31) || (int64_t)(2 * W + 18) * ldx * 4 >= (1ll << 31)) return 0;
   WgradArgs a;
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = (int)M;

@@ -108,6 +108,8 @@ GRAD_CASES = [
     (64, 13, 13, 64, 512, 3),   # dgrad/wgrad at the 13x13 benchmark grid (split-K dgrad)
     (4, 3, 3, 64, 64, 3),       # tiny maps: fewer pixels than one staged chunk, W < 8
     (3, 9, 11, 128, 64, 3),     # W < 16: the LDS-direct wgrad loader wraps image rows twice per chunk
+    (1, 9, 11, 32, 128, 3),     # Cin 32: two filter taps folded into one 64-column wgrad tile (128-cout tile)
+    (2, 16, 20, 32, 64, 3),     # same, 64-cout tile (layer 2 of yolo-pose.cfg)
 ]
 
 
