@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--cfg', default=os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--opt', default='', help='kernel experiment knobs, name=value,... (ssp_set_option); default: none')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -119,6 +120,9 @@ def main():
 
     if world > 1:
         init_distributed()
+    for kv in filter(None, args.opt.split(',')):
+        name, val = kv.split('=')
+        _lib.call('ssp_set_option', name.encode(), int(val))
 
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = Darknet(args.cfg).to(device).train()

@@ -21,12 +21,43 @@ struct WgradArgs {
   float* dw;
   int H, W, Cin, Cout, lddy, ldx, R, M;
   int ntile_co, ntile_ci, nsplit, chunk_m;
+  int no_store;   // timing probe (wgrad_variant 9): skip the atomic epilogue - results are wrong on purpose
   int fold;   // filter taps per cin tile: 1, or BNI / Cin when Cin < BNI (thin layers: two taps of 32 cins share a tile)
 };
 
 #define SSP_OOB 0x80000000u
 
-template <int BMO, int BNI, int NSLOT = 4>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// T consecutive floats from the LDS in one ds_read_b32 / b64 / b128
+template <int T>
+__device__ __forceinline__ void lds_read_vec(const char* ptr, float (&out)[T]) {
+  static_assert(T == 1 || T == 2 || T == 4, "1, 2 or 4 MFMA blocks per wave along a tile edge");
+  if constexpr (T == 1) {
+    out[0] = *reinterpret_cast<const float*>(ptr);
+  } else if constexpr (T == 2) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(ptr);
+    out[0] = v[0]; out[1] = v[1];
+  } else {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+  }
+}
+
+// mask bit of the lane set -> a, else b: ONE VALU instruction for a wave-uniform 64-bit lane mask held in SGPRs
+__device__ __forceinline__ unsigned lane_select(unsigned long long mask, unsigned a, unsigned b) {
+  unsigned r = b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+#endif
+  return r;
+}
+
+// FOLD: tiles that span several filter taps (Cin < BNI); their border test is per lane.  Otherwise the tap is uniform
+// over the workgroup and the border test runs on the scalar unit (see the loader below).
+// BVEC: also interleave the cin blocks (one vector read for the X operands too).  Fewer LDS instructions, but the
+// lanes of an atomic then step TN floats apart and touch twice the cache lines - kept as an experiment.
+template <int BMO, int BNI, int NSLOT = 4, bool FOLD = false, bool BVEC = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int RA = 16, WM = 2, WN = 2;
@@ -54,13 +85,23 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   const int niter = (m_end - m_begin + RA - 1) / RA;
   if (niter <= 0) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the scalar pixel walker depends on it
   const int wm = wid / WN, wn = wid % WN;
   const int li = lane & 31, lh = lane >> 5;
 
   // ---- loader lanes: piece g (1 KiB) of a tile = bytes [g*1024, g*1024+1024) of the row-major [16][C] image ----
+  // A 1-KiB piece of the X tile covers RP consecutive pixel rows (BNI = 128: 2 rows of 512 B, BNI = 64: 4 rows of
+  // 256 B), i.e. LPR = 64 / RP lanes per pixel.  Without FOLD the filter tap is uniform, so "does this pixel's tap
+  // fall inside the image" is a per-pixel-row question: the (x, y) of each of the wave's BPW * RP rows live in SGPRs,
+  // walk 16 pixels per chunk on the scalar unit, and reach the lanes as one 64-bit lane mask -> one v_cndmask per
+  // load.  (The fp32 MFMA shares the vector lanes with the VALU; the scalar unit is free.)
+  constexpr int RP = 1024 / (BNI * 4), LPR = 64 / RP;
+  static_assert(RP == 2 || RP == 4, "BNI is 64 or 128");
   unsigned a_voff[APW], b_off[BPW];
-  int b_row[BPW], b_x[BPW], b_y[BPW], b_dx[BPW], b_dy[BPW];
+  int b_row[BPW], b_x[BPW], b_y[BPW], b_dx[BPW], b_dy[BPW];   // FOLD: per-lane walker
+  int s_x[BPW][RP], s_y[BPW][RP];                             // !FOLD: scalar walker
+  const int dy0 = tap / p.R - pad, dx0 = tap % p.R - pad;
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int byte = (wid + 4 * j) * 1024 + lane * 16;
@@ -72,61 +113,106 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     const int byte = (wid + 4 * j) * 1024 + lane * 16;
     const int row = byte / (BNI * 4), col = (byte % (BNI * 4)) / 4;
     b_row[j] = row;
-    // tile column -> (tap, cin): with fold > 1 the tile spans `fold` consecutive taps of all Cin channels; the tap's
-    // pixel shift goes into the lane offset (relative to the pixel-row base of the descriptor)
-    const int tl = (p.fold > 1) ? tap + col / p.Cin : tap;
-    const int cc = (p.fold > 1) ? col % p.Cin : ci0 + col;
+    // tile column -> (tap, cin): with FOLD the tile spans `fold` consecutive taps of all Cin channels; the tap's pixel
+    // shift goes into the lane offset (the descriptor base sits at pixel (y-1, x-1) of the chunk's first row)
+    const int tl = FOLD ? tap + col / p.Cin : tap;
+    const int cc = FOLD ? col % p.Cin : ci0 + col;
     b_dy[j] = tl / p.R - pad;
     b_dx[j] = tl % p.R - pad;
     b_off[j] = (cc < p.Cin && tl < taps) ? (unsigned)(((row + b_dy[j] * p.W + b_dx[j] + p.W + 1) * p.ldx + cc) * 4) : SSP_OOB;
     const int m = m_begin + row;
     b_x[j] = m % p.W;
     b_y[j] = (m / p.W) % p.H;
+#pragma unroll
+    for (int t = 0; t < RP; ++t) {
+      const int ms = m_begin + (wid + 4 * j) * RP + t;
+      s_x[j][t] = ms % p.W;
+      s_y[j][t] = (ms / p.W) % p.H;
+    }
   }
+  const unsigned oob = SSP_OOB;
 
-  int ld_m = m_begin;   // first pixel of the chunk the loader stages next
-  auto issue_loads = [&](int slot_bytes) {
+  // Loader state for the NEXT chunk to stage (descriptors + lane offsets), prepared one step ahead: prep_next() is all
+  // scalar work (plus one v_cndmask per X piece) and sits inside the MFMA block of the previous step, where the
+  // scalar unit is otherwise idle; issue() at the top of a step is then nothing but the buffer loads.
+  int ld_m = m_begin;   // first pixel of the chunk prep_next() prepares
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  unsigned b_voff[BPW];
+  auto prep_next = [&]() {
     const int left = m_end - ld_m;                       // pixel rows still inside this workgroup's range
     const int64_t abase = (int64_t)ld_m * p.lddy;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.dy + abase), 0, left > 0 ? (int)min((int64_t)left * p.lddy * 4, (int64_t)0x7fffffff) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + ((int64_t)ld_m - p.W - 1) * p.ldx), 0, (int)SSP_OOB, 0x00020000);   // base = pixel (y-1, x-1)
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      if constexpr (FOLD) {
+        const int yy = b_y[j] + b_dy[j], xx = b_x[j] + b_dx[j];
+        const bool ok = (b_row[j] < left) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+        b_voff[j] = ok ? b_off[j] : SSP_OOB;
+        // walk this lane's pixel 16 positions ahead (W may be smaller than 16: up to two row wraps)
+        int x = b_x[j] + RA, y = b_y[j];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const bool wrap = x >= p.W;
+          x -= wrap ? p.W : 0;
+          y += wrap ? 1 : 0;
+          y = (y >= p.H) ? 0 : y;
+        }
+        b_x[j] = x;
+        b_y[j] = y;
+      } else {
+        unsigned long long mask = 0ull;
+#pragma unroll
+        for (int t = 0; t < RP; ++t) {
+          const int yy = s_y[j][t] + dy0, xx = s_x[j][t] + dx0;
+          const bool ok = ((wid + 4 * j) * RP + t < left) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+          constexpr unsigned long long rowmask = (LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull);
+          mask |= ok ? (rowmask << (t * LPR)) : 0ull;
+          int x = s_x[j][t] + RA, y = s_y[j][t];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const bool wrap = x >= p.W;
+            x -= wrap ? p.W : 0;
+            y += wrap ? 1 : 0;
+            y = (y >= p.H) ? 0 : y;
+          }
+          s_x[j][t] = x;
+          s_y[j][t] = y;
+        }
+        b_voff[j] = lane_select(mask, b_off[j], oob);
+      }
+    }
+    ld_m += RA;
+  };
+  auto issue = [&](int slot_bytes) {
 #pragma unroll
     for (int j = 0; j < APW; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds + slot_bytes + (wid + 4 * j) * 1024),
                                                16, a_voff[j], 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-      const int yy = b_y[j] + b_dy[j], xx = b_x[j] + b_dx[j];
-      const bool ok = (b_row[j] < left) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+    for (int j = 0; j < BPW; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds + slot_bytes + ABYTES + (wid + 4 * j) * 1024),
-                                               16, ok ? b_off[j] : SSP_OOB, 0, 0, 0);
-      // walk this lane's pixel 16 positions ahead (W may be smaller than 16: up to two row wraps)
-      int x = b_x[j] + RA, y = b_y[j];
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        const bool wrap = x >= p.W;
-        x -= wrap ? p.W : 0;
-        y += wrap ? 1 : 0;
-        y = (y >= p.H) ? 0 : y;
-      }
-      b_x[j] = x;
-      b_y[j] = y;
-    }
-    ld_m += RA;
+                                               16, b_voff[j], 0, 0, 0);
   };
 
-  // ---- operand fetch: k-step kk uses pixel rows 2kk + lh; A[i=cout][k], B[k][j=cin]; conflict-free ds_read_b32 ----
-  const unsigned fa_base = (unsigned)(lh * BMO + wm * WTM + li) * 4u;
-  const unsigned fb_base = (unsigned)ABYTES + (unsigned)(lh * BNI + wn * WTN + li) * 4u;
+  // ---- operand fetch: k-step kk uses pixel rows 2kk + lh.  The wave's TM (TN) 32-row MFMA blocks are INTERLEAVED
+  // over its WTM couts (WTN cins): block i holds couts {wm*WTM + TM*r + i}, so a lane's TM operands of one k-step are
+  // TM consecutive floats of a pixel row - one ds_read_b64 / b128 with a 16-bit immediate offset (no address VALU) ----
+  const unsigned fa_base = (unsigned)(lh * BMO + wm * WTM + li * TM) * 4u;
+  // The cin blocks stay contiguous (block j = cins wn*WTN + 32j + li): the 32 lanes of an atomic in the epilogue then
+  // cover one 128-byte line of the gradient; their operands are TN conflict-free ds_read_b32.
+  const unsigned fb_base = (unsigned)ABYTES + (unsigned)(lh * BNI + wn * WTN + (BVEC ? li * TN : li)) * 4u;
   auto read_frag = [&](int slot_bytes, int kk, float (&av)[TM], float (&bv)[TN]) {
+    lds_read_vec<TM>(lds + slot_bytes + fa_base + kk * 2 * BMO * 4, av);
+    if constexpr (BVEC) {
+      lds_read_vec<TN>(lds + slot_bytes + fb_base + kk * 2 * BNI * 4, bv);
+    } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      av[i] = *reinterpret_cast<const float*>(lds + slot_bytes + fa_base + (kk * 2 * BMO + i * 32) * 4);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      bv[j] = *reinterpret_cast<const float*>(lds + slot_bytes + fb_base + (kk * 2 * BNI + j * 32) * 4);
+      for (int j = 0; j < TN; ++j)
+        bv[j] = *reinterpret_cast<const float*>(lds + slot_bytes + fb_base + (kk * 2 * BNI + j * 32) * 4);
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -138,7 +224,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int c = 0; c < NSLOT - 1; ++c) issue_loads(c * SLOTB);
+  for (int c = 0; c < NSLOT - 1; ++c) { prep_next(); issue(c * SLOTB); }
+  prep_next();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -152,12 +239,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   auto step = [&](auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     constexpr int S1 = (S + 1) % NSLOT, SL = (S + NSLOT - 1) % NSLOT, P = (NSLOT == 4) ? (S & 1) : 0;
-    issue_loads(SL * SLOTB);
+    issue(SL * SLOTB);
     float av[7][TM], bv[7][TN];
 #pragma unroll
     for (int kk = 1; kk < 8; ++kk) read_frag(S * SLOTB, kk, av[kk - 1], bv[kk - 1]);
     if constexpr (NSLOT == 4) read_frag(S1 * SLOTB, 0, a0[P ^ 1], b0[P ^ 1]);   // published by the previous barrier
     __builtin_amdgcn_sched_barrier(0);
+    prep_next();                             // scalar work for the next step's loads, free to interleave with the MFMAs
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -199,32 +287,34 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (p.no_store && acc[0][0][0] != 12345.678f) return;
 
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = wn * WTN + j * 32 + li;
-      const int tl = (p.fold > 1) ? tap + col / p.Cin : tap;
-      const int ci = (p.fold > 1) ? col % p.Cin : ci0 + col;
+      const int col = wn * WTN + (BVEC ? li * TN + j : j * 32 + li);
+      const int tl = FOLD ? tap + col / p.Cin : tap;
+      const int ci = FOLD ? col % p.Cin : ci0 + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + wm * WTM + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
         if (co < p.Cout && ci < p.Cin && tl < taps) atomicAdd(p.dw + ((int64_t)co * taps + tl) * p.Cin + ci, acc[i][j][r]);
       }
     }
 #endif
 }
 
-template <int BMO, int BNI, int NSLOT = 4>
+template <int BMO, int BNI, int NSLOT = 4, bool FOLD = false, bool BVEC = false>
 static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   constexpr int RA = 16;
   a.ntile_co = ssp_cdiv(a.Cout, BMO);
   a.ntile_ci = ssp_cdiv(a.Cin, BNI);
-  a.fold = (a.Cin < BNI && BNI % a.Cin == 0 && a.R > 1) ? BNI / a.Cin : 1;
+  a.fold = FOLD ? BNI / a.Cin : 1;
+  a.no_store = ssp_option(SSP_OPT_WGRAD_VARIANT) == 9;
   const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold);
   const int lds_bytes = NSLOT * RA * (BMO + BNI) * 4;
-  auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT>;
+  auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>;
   static int configured = 0;
   static int slots = 0;
   if (lds_bytes > configured) {
@@ -238,9 +328,15 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
       per_cu = 2;
     slots = per_cu * 256;
   }
-  // whole resident waves of workgroups, 2..5 of them, >= 8 chunks per workgroup (as conv_wgrad.hip)
+  // Split over pixels.  Every workgroup ends with BMO x BNI atomics onto its filter tile, and all workgroups of a tile
+  // hit the same lines: on the layers with few tiles (layers 4-16: 9-72 tiles) the atomic traffic is 5-12 % of the
+  // launch, so the split is the SMALLEST one that fills whole resident waves of workgroups (>= 93 % of the last wave),
+  // from one wave up to five; only when no split gets there the best-filling one wins.  >= 8 chunks per workgroup.
+  const int variant = ssp_option(SSP_OPT_WGRAD_VARIANT);
   const int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);
-  int64_t lo = (2 * (int64_t)slots + tiles - 1) / tiles, hi = (5 * (int64_t)slots) / tiles;
+  int64_t lo = ((int64_t)slots + tiles - 1) / tiles, hi = (5 * (int64_t)slots) / tiles;
+  if (tiles >= (int64_t)(0.93 * slots)) lo = 1;        // the tiles alone (almost) fill a wave
+  if (variant == 4) lo = (2 * (int64_t)slots + tiles - 1) / tiles;   // experiment: at least two waves (the old rule)
   if (lo < 1) lo = 1;
   if (hi < lo) hi = lo;
   if (lo > max_split) lo = max_split;
@@ -251,6 +347,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
     const double waves = (double)(tiles * sp) / slots;
     const double eff = waves / (double)((tiles * sp + slots - 1) / slots);
     if (eff > best + 1e-3) { best = eff; nsplit = sp; }
+    if (eff >= 0.93) break;
   }
   int64_t chunk = (a.M + nsplit - 1) / nsplit;
   chunk = (chunk + RA - 1) / RA * RA;
@@ -274,9 +371,17 @@ int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, in
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = (int)M;
   int rc;
-  // 256-cout tiles (128x64 per wave): 25-50 % fewer LDS reads, DMA pieces and border walks per MFMA than 128x128
-  if (Cout >= 256 && Cin >= 128 && ssp_option(SSP_OPT_WGRAD_VARIANT) != 3) rc = launch_wgrad_dma<256, 128, 3>(a, stream);
-  else if (Cout >= 128 && Cin >= 128) rc = launch_wgrad_dma<128, 128>(a, stream);
+  const int wv = ssp_option(SSP_OPT_WGRAD_VARIANT);
+  if (Cin == 32) rc = (Cout >= 128) ? launch_wgrad_dma<128, 64, 4, true>(a, stream) : launch_wgrad_dma<64, 64, 4, true>(a, stream);
+  // 256-cout tiles (128x64 per wave) on a 3-slot ring, two workgroups per CU: fewer LDS reads, DMA pieces and border
+  // walks per MFMA than 128x128, and - what decides it inside the training step, where the data-gradient kernel runs
+  // concurrently on the other stream - two fat workgroups per CU leave that kernel room (whole-step A/B on one box:
+  // 50.8 ms against 52.3 ms for 128x128 tiles at three per CU, although the stand-alone launch times are equal)
+  else if (Cout >= 256 && Cin >= 128 && wv != 8) rc = launch_wgrad_dma<256, 128, 3>(a, stream);
+  else if (Cout >= 128 && Cin >= 128 && wv == 6) rc = launch_wgrad_dma<128, 128, 3, false, true>(a, stream);   // experiment
+  else if (Cout >= 128 && Cin >= 128 && wv == 3) rc = launch_wgrad_dma<128, 128, 4>(a, stream);           // experiment
+  // 3-slot ring: 48 KB of LDS, three workgroups per CU (measured +3..6 % over the 4-slot ring at two per CU)
+  else if (Cout >= 128 && Cin >= 128) rc = launch_wgrad_dma<128, 128, 3>(a, stream);
   else if (Cout >= 128) rc = launch_wgrad_dma<128, 64>(a, stream);
   else if (Cin >= 128) rc = launch_wgrad_dma<64, 128>(a, stream);
   else rc = launch_wgrad_dma<64, 64>(a, stream);
