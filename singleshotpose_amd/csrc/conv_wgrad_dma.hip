@@ -163,24 +163,27 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
         b_x[j] = x;
         b_y[j] = y;
       } else {
-        unsigned long long mask = 0ull;
+        // branch-free scalar code (bitwise tests, selects) so that it stays in the MFMA block's basic block
+        unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
         for (int t = 0; t < RP; ++t) {
           const int yy = s_y[j][t] + dy0, xx = s_x[j][t] + dx0;
-          const bool ok = ((wid + 4 * j) * RP + t < left) && ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
-          constexpr unsigned long long rowmask = (LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull);
-          mask |= ok ? (rowmask << (t * LPR)) : 0ull;
+          const int ok = (int)((wid + 4 * j) * RP + t < left) & (int)((unsigned)yy < (unsigned)p.H) & (int)((unsigned)xx < (unsigned)p.W);
+          constexpr unsigned rowmask = (LPR == 32) ? 0xffffffffu : 0xffffu;
+          const unsigned bits = (0u - (unsigned)ok) & (rowmask << ((t * LPR) & 31));
+          if (t * LPR < 32) mlo |= bits; else mhi |= bits;
           int x = s_x[j][t] + RA, y = s_y[j][t];
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
-            const bool wrap = x >= p.W;
-            x -= wrap ? p.W : 0;
-            y += wrap ? 1 : 0;
-            y = (y >= p.H) ? 0 : y;
+            const int wrap = (int)(x >= p.W);
+            x -= (0 - wrap) & p.W;
+            y += wrap;
+            y &= 0 - (int)(y < p.H);
           }
           s_x[j][t] = x;
           s_y[j][t] = y;
         }
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
         b_voff[j] = lane_select(mask, b_off[j], oob);
       }
     }
