@@ -16,6 +16,7 @@ reported together in `roofline_bwd`.  `cpu_baseline` times the CPU oracle of the
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -84,7 +85,10 @@ def forward_traffic_per_launch():
     data = json.load(open(files[-1]))
     tot, n = 0.0, 0
     for name, v in data.items():
-        fwd = ('conv_igemm_dma_kernel' in name and ', 0>' in name) or ('conv_igemm_kernel' in name)
+        # conv_igemm_dma_kernel<BM, BN, PASS, ...> and conv_igemm_kernel<BM, BN, WM, WN, BK, ABL, PASS> (first layer):
+        # PASS 0 = forward launches, 1 = data-gradient launches of the same code
+        fwd = (re.search(r'conv_igemm_dma_kernel<\d+, \d+, 0[,>]', name) is not None or
+               re.search(r'conv_igemm_kernel<(\d+, ){6}0>', name) is not None)
         if fwd:
             tot += v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch_reported'])
             n += v['launches']
@@ -203,7 +207,7 @@ def main():
             "config": {"workload": "cfg/yolo-pose.cfg train step (zero_grad+fwd+RegionLoss+bwd+grad all-reduce+SGD), "
                                    "%dx%d, batch %d/GPU, random-init weights, 1 label/image" % (H, W, B),
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_dma_kernel<*,*,0> / conv_igemm_kernel forward launches",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_dma_kernel<*,*,0,...> / conv_igemm_kernel forward launches",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

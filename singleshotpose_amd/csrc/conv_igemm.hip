@@ -30,7 +30,8 @@
 // so after a barrier the matrix cores restart from registers, and neither the LDS round trip nor the HBM/L2 latency of
 // a chunk sits between two MFMA blocks.  Loads are branch-free: out-of-image taps read a clamped address and are
 // zeroed with v_cndmask; rows/columns beyond M/Cout read row 0 / the last filter and are never stored.
-template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
+// PASS (0 forward, 1 data gradient) only gives the two uses distinct kernel names for profiles (as conv_igemm_dma.hip)
+template <int BM, int BN, int WM, int WN, int BK, int ABL = 0, int PASS = 0>
 __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int LS = BK + 4;        // LDS row stride in floats (16-B aligned, conflict-free b128 reads)
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int BK, int ABL = 0, int PASS = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
@@ -349,7 +350,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(WM * WN * 64);
   const int lds_bytes = 3 * (BM + BN) * (BK + 4) * 4 + extra_lds;
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, ABL>;
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, ABL, PASS>;
   static int configured = 0;   // per instantiation
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
@@ -434,6 +435,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
+  a.probe = 0;
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
   a.ksplit = pl.ksplit;
   a.ws = ws;
@@ -467,13 +469,14 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     if (bk >= 16 && variant != 50 && ((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
       rc = ssp_conv_igemm_dma_launch(a, pl.bm, pl.slots, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
     } else if (pl.bm == 64) {
-      rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream);
+      rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream)
+                      : (prof_kind == SSP_PROF_CONV_DGRAD ? launch_cfg<64, 128, 2, 2, 4, 0, 1>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream));
     } else if (bk == 32) {
       rc = launch_cfg<128, 128, 2, 2, 32>(a, stream);
     } else if (bk == 16) {
       rc = launch_cfg<128, 128, 2, 2, 16>(a, stream);
     } else {
-      rc = launch_cfg<128, 128, 2, 2, 4>(a, stream);
+      rc = prof_kind == SSP_PROF_CONV_DGRAD ? launch_cfg<128, 128, 2, 2, 4, 0, 1>(a, stream) : launch_cfg<128, 128, 2, 2, 4>(a, stream);
     }
   } else if (Cout > 32) {
     if (pl.bm == 128) {

@@ -16,6 +16,7 @@ struct ConvArgs {
   int xcd_remap;
   float* ws;           // split-K partial tiles [ksplit][M][Cout] (ksplit > 1)
   int ksplit, it_per_split;
+  int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
 };
 
 __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {

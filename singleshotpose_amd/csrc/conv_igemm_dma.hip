@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  if (p.probe == 1 && acc[0][0][0] != 12345.678f) return;
   igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid);
 #endif
 }
@@ -235,6 +236,7 @@ static int launch_dma(ConvArgs a, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
   const int niter_total = a.R * a.R * (a.Cin / 16);
+  a.probe = ssp_option(SSP_OPT_IGEMM_VARIANT) == 60 ? 1 : 0;
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);

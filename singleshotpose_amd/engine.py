@@ -30,6 +30,29 @@ _WEIGHTS_EPOCH = [0]
 # autotuned igemm plan per launch shape, shared by every Plan of the process: multi-scale training (dataset.py:66-90
 # draws a new resolution every 10 batches) revisits the same ~20 shapes, each is timed once
 _TUNE_CACHE = {}
+_TUNE_CACHE_FILE = [None]      # SSP_TUNE_CACHE=<json file>: loaded once, rewritten whenever a new shape was timed
+
+
+def _tune_cache_load():
+    path = os.environ.get('SSP_TUNE_CACHE')
+    if not path or _TUNE_CACHE_FILE[0] == path:
+        return
+    _TUNE_CACHE_FILE[0] = path
+    if os.path.isfile(path):
+        import json
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                _TUNE_CACHE.setdefault(tuple(json.loads(k)), int(v))
+
+
+def _tune_cache_save():
+    path = _TUNE_CACHE_FILE[0]
+    if path:
+        import json
+        tmp = path + '.tmp.%d' % os.getpid()
+        with open(tmp, 'w') as f:
+            json.dump({json.dumps(list(k)): v for k, v in _TUNE_CACHE.items()}, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
 
 
 def weights_changed():
@@ -250,11 +273,14 @@ class Plan(object):
         """Times the candidate igemm plans (tile rows x split-K x LDS ring depth) of every eligible conv launch of this
         input shape on the real buffers and keeps the fastest (per-shape tile selection).
         The library's shape heuristic is within ~5-15 % of the best choice on some layers; which plan wins depends on
-        how the grid fills the 256 CUs.  One-off cost per (B,H,W): ~1 s for yolo-pose.cfg.  SSP_AUTOTUNE=0 disables."""
+        how the grid fills the 256 CUs.  One-off cost per (B,H,W): ~1 s for yolo-pose.cfg.  SSP_AUTOTUNE=0 disables;
+        SSP_TUNE_CACHE=<file> keeps the timed choices across processes (JSON)."""
         B = self.B
         call = _lib.call
         st = torch.cuda.current_stream().cuda_stream
         f32 = dict(dtype=torch.float32, device=self.device)
+        _tune_cache_load()
+        n_known = len(_TUNE_CACHE)
         cands = (12813, 12814, 6414, 6413, 12824, 12834)
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
@@ -306,6 +332,8 @@ class Plan(object):
                                         ('dgrad', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld))
         call('ssp_set_option', b'igemm_plan', 0)
         torch.cuda.synchronize()
+        if len(_TUNE_CACHE) != n_known:
+            _tune_cache_save()
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training, need_grad=False):

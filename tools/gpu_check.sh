@@ -1,8 +1,12 @@
 #!/bin/bash
 # One GPU-box visit: gpu tests, smoke, bench line, rocprofv3 kernel stats, HBM-traffic PMC passes.  Usage: tools/gpu_check.sh [tag]
 TAG=${1:-r01}
-mkdir -p gpurun_out
+mkdir -p gpurun_out gpurun_out/pmc_traffic_$TAG
 export TMPDIR=/tmp
+# the bench run times the per-shape kernel plans once and saves them; the profiled runs below reuse them, so their
+# kernel statistics contain the training step's launches only (no autotune trial launches)
+export SSP_TUNE_CACHE=$(pwd)/gpurun_out/tune_cache_$TAG.json
+rm -f $SSP_TUNE_CACHE
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/pytest_$TAG.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err

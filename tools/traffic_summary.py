@@ -22,5 +22,4 @@ for k, d in agg.items():
         'write_bytes_per_launch_reported': 1024.0 * sum(write) / max(len(write), 1),
     }
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
-fwd = [v for k, v in res.items() if 'igemm' in k and (', 0>' in k or 'igemm_kernel' in k)]
 print(json.dumps({k: v for k, v in list(res.items())[:40]}, indent=1)[:3000])
