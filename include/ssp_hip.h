@@ -88,6 +88,9 @@ int ssp_u8hwc_to_nhwc(const unsigned char* src, float* dst, int B, int H, int W,
 int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream);
 /* conv.weight -> [Cin][R*R][Coutp], taps flipped */
 int ssp_repack_dgrad(const float* w, float* out, int Cout, int Cin, int Coutp, int R, void* stream);
+/* same operand from filters stored channels-last, [Cout][R*R][Cin] (a torch.channels_last conv.weight): that layout IS
+ * the forward operand and the layout ssp_conv_wgrad accumulates, so such parameters need no other repack */
+int ssp_repack_dgrad_packed(const float* wp, float* out, int Cout, int Cin, int Coutp, int R, void* stream);
 /* packed gradient [Cout][R*R][Cinp] -> (Cout,Cin,R,R) */
 int ssp_unpack_grad(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, void* stream);
 /* Reorg(2) (darknet.py:16-35) on NHWC: dst[b,y/2,x/2,((y&1)*2+(x&1))*C+c] = src[b,y,x,c]; backward = inverse */

@@ -45,6 +45,7 @@ _SIGS = {
     "ssp_u8hwc_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_repack_fwd": [P, P, I, I, I, I, P],
     "ssp_repack_dgrad": [P, P, I, I, I, I, P],
+    "ssp_repack_dgrad_packed": [P, P, I, I, I, I, P],
     "ssp_unpack_grad": [P, P, I, I, I, I, P],
     "ssp_reorg": [P, I, P, I, I, I, I, I, I, I, P],
     "ssp_copy_channels": [P, I, P, I, I, L, I, P],

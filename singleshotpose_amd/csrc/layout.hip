@@ -144,6 +144,27 @@ __global__ void __launch_bounds__(256) repack_dgrad_kernel(const float* __restri
   }
 }
 
+// Same operand from filters already stored channels-last, [Cout][R*R][Cin] (the forward operand layout, which is also
+// what a torch.channels_last conv.weight is in memory): out[ci][t][co] = wp[co][taps-1-t][ci] - one plain 32x32 LDS
+// transpose per filter tap, 128-byte runs on both sides.
+__global__ void __launch_bounds__(256) repack_dgrad_packed_kernel(const float* __restrict__ wp, float* __restrict__ out,
+                                                                  int Cout, int Cin, int Coutp, int taps) {
+  __shared__ float tile[32][33];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, t = blockIdx.z;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = r0; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + c;
+    tile[r][c] = (co < Cout && ci < Cin) ? wp[((int64_t)co * taps + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = r0; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + c;
+    if (ci < Cin && co < Coutp) out[((int64_t)ci * taps + (taps - 1 - t)) * Coutp + co] = tile[c][r];
+  }
+}
+
 // space-to-depth, stride 2, NHWC: out[b,hy,wx,(dy*2+dx)*C + c] = in[b,2hy+dy,2wx+dx,c]
 // dir = 0: forward gather (in -> out); dir = 1: backward scatter (gradient: out-layout -> in-layout)
 __global__ void __launch_bounds__(256) reorg_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
@@ -337,6 +358,16 @@ int ssp_repack_dgrad_launch(const float* w, float* out, int Cout, int Cin, int C
   hipLaunchKernelGGL(repack_dgrad_kernel, dim3(ssp_cdiv(Cin, 32), ssp_cdiv(Coutp, 32)), dim3(256), 0, stream, w, out,
                      Cout, Cin, Coutp, R * R);
   SSP_CHECK_LAUNCH("repack_dgrad");
+  return SSP_OK;
+}
+
+int ssp_repack_dgrad_packed_launch(const float* wp, float* out, int Cout, int Cin, int Coutp, int R, hipStream_t stream) {
+  SSP_CHECK_ARG(R == 1 || R == 3, "repack_dgrad_packed: R must be 1 or 3");
+  SSP_CHECK_ARG(Coutp >= Cout && Cout > 0 && Cin > 0, "repack_dgrad_packed: need Coutp >= Cout > 0, Cin > 0");
+  SspProfScope prof(SSP_PROF_LAYOUT, stream, 8.0 * Cout * Cin * R * R);
+  hipLaunchKernelGGL(repack_dgrad_packed_kernel, dim3(ssp_cdiv(Cin, 32), ssp_cdiv(Coutp, 32), R * R), dim3(256), 0, stream,
+                     wp, out, Cout, Cin, Coutp, R * R);
+  SSP_CHECK_LAUNCH("repack_dgrad_packed");
   return SSP_OK;
 }
 

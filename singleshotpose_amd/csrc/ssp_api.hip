@@ -40,6 +40,7 @@ int ssp_u8hwc_to_nhwc_launch(const unsigned char* src, float* dst, int B, int H,
 int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
 int ssp_unpack_grad_launch(const float* dwp, float* grad, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
 int ssp_repack_dgrad_launch(const float* w, float* out, int Cout, int Cin, int Coutp, int R, hipStream_t stream);
+int ssp_repack_dgrad_packed_launch(const float* wp, float* out, int Cout, int Cin, int Coutp, int R, hipStream_t stream);
 int ssp_reorg_launch(const float* src, int lds_, float* dst, int ldd, int C, int B, int H, int W, int backward,
                      int accumulate, hipStream_t stream);
 int ssp_copy_channels_launch(const float* src, int lds_, float* dst, int ldd, int C, int64_t M, int accumulate,
@@ -190,6 +191,9 @@ int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, i
 }
 int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream) {
   return ssp_repack_fwd_launch(w, out, Cout, Cin, Cinp, R, (hipStream_t)stream);
+}
+int ssp_repack_dgrad_packed(const float* wp, float* out, int Cout, int Cin, int Coutp, int R, void* stream) {
+  return ssp_repack_dgrad_packed_launch(wp, out, Cout, Cin, Coutp, R, (hipStream_t)stream);
 }
 int ssp_repack_dgrad(const float* w, float* out, int Cout, int Cin, int Coutp, int R, void* stream) {
   return ssp_repack_dgrad_launch(w, out, Cout, Cin, Coutp, R, (hipStream_t)stream);

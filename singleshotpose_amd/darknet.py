@@ -102,6 +102,15 @@ class Darknet(nn.Module):
                     model.add_module('bn{0}'.format(conv_id), nn.BatchNorm2d(filters, eps=1e-4))
                 else:
                     model.add_module('conv{0}'.format(conv_id), nn.Conv2d(prev_filters, filters, k, stride, pad))
+                # Filters are kept channels-last in memory ([Cout][kh][kw][Cin]; shape, values and the .weights format
+                # are unchanged): that is the forward GEMM operand and the layout the filter gradient is accumulated in,
+                # so the kernels use parameter and gradient in place instead of repacking 202 MB three times a step.
+                # .cuda() / load_weights / load_state_dict / optimizers preserve it.
+                # (Layers whose input channels are not a multiple of 4 - the 3-channel first layer - are padded on the
+                # way to the kernels, so they keep the plain layout and the small repack.)
+                conv = model[0]
+                if prev_filters % 4 == 0:
+                    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
                 if block['activation'] == 'leaky':
                     model.add_module('leaky{0}'.format(conv_id), nn.LeakyReLU(0.1, inplace=True))
                 elif block['activation'] == 'relu':

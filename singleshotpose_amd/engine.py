@@ -59,6 +59,13 @@ def weights_changed():
     _WEIGHTS_EPOCH[0] += 1
 
 
+def _is_packed(wt, cinp):
+    """True when the (Cout,Cin,kh,kw) parameter is stored channels-last, i.e. [Cout][kh][kw][Cin] in memory with no channel
+    padding needed: that is the forward operand layout and the layout the filter gradient is accumulated in, so the
+    kernels read / write the parameter (and its gradient) in place."""
+    return wt.size(1) == cinp and wt.permute(0, 2, 3, 1).is_contiguous()
+
+
 def _ptr(t, offset=0):
     return t.data_ptr() + 4 * offset
 
@@ -351,13 +358,18 @@ class Plan(object):
         # under the MFMA-bound forward convs instead of sitting on the critical path of backward.
         # eval: repack only when a parameter changed (in-place updates bump _version, the fused SGD bumps the weights
         # epoch, load_weights invalidates explicitly); training: weights change every step, always repack.
+        # Parameters stored channels-last (Darknet builds them that way) ARE the forward operand: nothing to repack.
         stale = []
         for op in self.ops_fwd:
             if op[0] == 'conv':
-                wt = op[1].conv.weight
+                cs = op[1]
+                wt = cs.conv.weight
+                cs.packed = _is_packed(wt, cs.cinp)
+                if cs.packed:
+                    continue
                 key = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
-                if training or self.wversion.get(op[1].ind) != key:
-                    stale.append((op[1], key))
+                if training or self.wversion.get(cs.ind) != key:
+                    stale.append((cs, key))
         wait_for = {}
         if stale or need_grad:
             if self.side_stream is None:
@@ -366,7 +378,10 @@ class Plan(object):
             side.wait_stream(torch.cuda.current_stream())
             for group in (stale[:4], stale[4:]):
                 for cs, key in group:
-                    call('ssp_repack_fwd', cs.conv.weight.data_ptr(), _ptr(self.wpack, cs.woff), cs.cout, cs.cin,
+                    with torch.cuda.stream(side):
+                        src = cs.conv.weight.detach().contiguous()      # the repack kernels read (Cout,Cin,kh,kw) order
+                        src.record_stream(side)
+                    call('ssp_repack_fwd', src.data_ptr(), _ptr(self.wpack, cs.woff), cs.cout, cs.cin,
                          cs.cinp, cs.k, side.cuda_stream)
                     self.wversion[cs.ind] = key
                 if group:
@@ -377,8 +392,13 @@ class Plan(object):
             for ind in sorted(self.convs.keys(), reverse=True):
                 cs = self.convs[ind]
                 if not cs.first:
-                    call('ssp_repack_dgrad', cs.conv.weight.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin,
-                         cs.coutp, cs.k, side.cuda_stream)
+                    src = cs.conv.weight.detach()
+                    if not cs.packed:
+                        with torch.cuda.stream(side):
+                            src = src.contiguous()
+                            src.record_stream(side)
+                    call('ssp_repack_dgrad_packed' if cs.packed else 'ssp_repack_dgrad', src.data_ptr(),
+                         _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp, cs.k, side.cuda_stream)
             self.dgrad_ready = side.record_event()
         else:
             self.dgrad_ready = None
@@ -394,9 +414,9 @@ class Plan(object):
                 bias = cs.conv.bias.data_ptr() if cs.conv.bias is not None else None
                 use_stats = cs.bn and training
                 call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
-                call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(), bias,
-                     cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
-                     cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
+                call('ssp_conv_fwd', cs.inp.ptr, cs.conv.weight.data_ptr() if cs.packed else _ptr(self.wpack, cs.woff),
+                     cs.raw.data_ptr(), bias, cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout,
+                     cs.inp.ld, cs.ldraw, cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
                 v = cs.vec
                 if cs.bn:
                     bn = cs.bnm
@@ -458,7 +478,9 @@ class Plan(object):
         if o.ld > o.C:
             raise NotImplementedError("network output channels must be a multiple of 4")
         written.add(self.last)
-        self.gpack.zero_()
+        for cs in self.convs.values():          # packed-gradient staging of the parameters that are not channels-last
+            if not cs.packed:
+                self.gpack[cs.woff:cs.woff + cs.cout * cs.k * cs.k * cs.cinp].zero_()
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
         if self.side_stream is None:
@@ -477,12 +499,15 @@ class Plan(object):
         out_grads = {}
         training = self.was_training
         # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
-        flat = torch.empty(self.grad_total, dtype=torch.float32, device=self.device)
+        # zeroed: the filter-gradient kernel accumulates channels-last parameters' gradients straight into it
+        flat = torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)
         flat.record_stream(side)
         self.last_flat_grad = flat
 
-        def gview(prm):
+        def gview(prm, channels_last=False):
             off, n, shape = self.grad_layout[id(prm)]
+            if channels_last:      # the parameter's own strides: [Cout][kh][kw][Cin] in memory
+                return torch.as_strided(flat, shape, prm.stride(), off)
             return flat[off:off + n].view(shape)
 
         def producer_of(act):
@@ -528,10 +553,14 @@ class Plan(object):
                     call('ssp_colsum', dy_ptr, dy_ld, cs.M, cs.cout, db.data_ptr(), st)
                     out_grads[id(cs.conv.bias)] = db
                 side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
-                call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp, cs.cout,
-                     dy_ld, cs.inp.ld, cs.k, st2)
-                gw = gview(cs.conv.weight)
-                call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
+                gw = gview(cs.conv.weight, cs.packed)
+                if cs.packed:       # accumulate in place: the gradient has the parameter's channels-last layout
+                    call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
+                         cs.inp.ld, cs.k, st2)
+                else:
+                    call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp,
+                         cs.cout, dy_ld, cs.inp.ld, cs.k, st2)
+                    call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
                 out_grads[id(cs.conv.weight)] = gw
                 if self.reducer is not None:
                     with torch.cuda.stream(side):   # the all-reduce of a finished bucket is ordered after its wgrads

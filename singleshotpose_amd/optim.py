@@ -21,6 +21,16 @@ from . import _lib
 from .engine import weights_changed
 
 
+def _dense(t):
+    """Contiguous, or channels-last (conv filters as Darknet keeps them): numel consecutive floats either way."""
+    return t.is_contiguous() or (t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous())
+
+
+def _same_layout(a, b):
+    """Same shape and the same strides on every dimension that has more than one element."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class SGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False):
         if lr < 0.0:
@@ -51,7 +61,10 @@ class SGD(torch.optim.Optimizer):
         items = []
         for p in params:
             g = p.grad
-            if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+            if g is None or g.dtype != torch.float32 or not g.is_cuda:
+                return None
+            # dense in memory with the parameter's own strides (contiguous, or channels-last conv filters)
+            if not (_dense(p) and _same_layout(g, p)):
                 return None
             st = g.untyped_storage()
             if base is None:
@@ -77,12 +90,16 @@ class SGD(torch.optim.Optimizer):
         layout = []
         for p, off in items:
             n = p.numel()
-            flat_p[off:off + n].copy_(p.data.reshape(-1))
+            # views with the parameter's own strides (channels-last filters stay channels-last), element for element
+            # at the offsets of the gradient views
+            pv = torch.as_strided(flat_p, p.shape, p.stride(), off)
+            mv = torch.as_strided(flat_m, p.shape, p.stride(), off)
+            pv.copy_(p.data)
             old = self.state.get(p, {}).get('momentum_buffer')
             if old is not None:
-                flat_m[off:off + n].copy_(old.reshape(-1))
-            p.data = flat_p[off:off + n].view(p.shape)
-            self.state[p]['momentum_buffer'] = flat_m[off:off + n].view(p.shape)
+                mv.copy_(old)
+            p.data = pv
+            self.state[p]['momentum_buffer'] = mv
             layout.append((p, off, n))
         self._flat_p, self._flat_m, self._layout = flat_p, flat_m, layout
 
@@ -140,10 +157,10 @@ class SGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.to(torch.float32).contiguous()
-                if not p.data.is_contiguous():
-                    raise RuntimeError("SGD: non-contiguous parameter")
+                if not _dense(p.data):
+                    raise RuntimeError("SGD: parameter is neither contiguous nor channels-last")
+                if g.dtype != torch.float32 or not _same_layout(g, p):
+                    g = torch.empty_like(p.data).copy_(g)      # same memory order as the parameter
                 state = self.state[p]
                 buf = state.get('momentum_buffer')
                 first = 0

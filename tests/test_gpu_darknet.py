@@ -293,3 +293,39 @@ def test_uint8_image_input_equals_totensor_path():
     assert rel_err(grads[0].cpu().numpy(), grads[1].cpu().numpy()) < 1e-5      # wgrad sums with fp32 atomics
     with pytest.raises(ValueError):
         model(torch.zeros(1, 3, 96, 96, dtype=torch.uint8, device='cuda'))
+
+
+def test_filters_are_channels_last_and_used_in_place():
+    """Darknet keeps conv filters channels-last in memory (same shape / values / .weights format): the kernels use the
+    parameter as the forward operand and accumulate its gradient in place.  A filter a caller replaced by a plain
+    contiguous tensor takes the repack path and must give the same numbers."""
+    from singleshotpose_amd.engine import _is_packed
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 5)
+    convs = [m for m in model.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert convs[0].weight.is_contiguous() and not _is_packed(convs[0].weight, 4)     # 3 input channels: padded path
+    for c in convs[1:]:
+        assert c.weight.is_cuda and c.weight.permute(0, 2, 3, 1).is_contiguous()
+        assert _is_packed(c.weight, c.weight.size(1))
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 3, 96, 96, generator=g).cuda()
+    probe = torch.randn(3, 20, 3, 3, generator=g).cuda()
+    model.zero_grad()
+    y1 = model(x)
+    (y1 * probe).sum().backward()
+    grads1 = [c.weight.grad.clone() for c in convs]
+    for c in convs[1:]:
+        assert c.weight.grad.stride() == c.weight.stride()           # gradient view has the parameter's layout
+    base = convs[1].weight.grad.untyped_storage().data_ptr()
+    assert all(c.weight.grad.untyped_storage().data_ptr() == base for c in convs)     # one flat buffer
+    # now the same network with plain contiguous filters (reference layout): repack / unpack path
+    for c in convs:
+        c.weight.data = c.weight.data.contiguous()
+        assert c.weight.is_contiguous()
+    model.zero_grad()
+    y2 = model(x)
+    (y2 * probe).sum().backward()
+    assert rel_err(y2.detach().cpu().numpy(), y1.detach().cpu().numpy()) < 1e-6
+    for c, g1 in zip(convs, grads1):
+        assert c.weight.grad.shape == g1.shape
+        assert rel_err(c.weight.grad.cpu().numpy(), g1.cpu().numpy()) < 2e-5      # fp32 atomics: order differs

@@ -163,6 +163,13 @@ def test_repack_bit_exact():
         refd = torch.zeros(ci, k * k, cop)
         refd[:, :, :co] = torch.flip(w.reshape(co, ci, k * k), dims=[2]).permute(1, 2, 0)
         assert torch.equal(gotd, refd)
+        # the same operand from channels-last filters ([Cout][kh][kw][Cin] in memory, what Darknet keeps)
+        wcl = w.to(G.dev()).contiguous(memory_format=torch.channels_last)
+        if k == 1:
+            wcl = w.to(G.dev()).permute(0, 2, 3, 1).contiguous()       # explicit [Cout][1][1][Cin] bytes
+        outp = torch.full((ci * k * k * cop,), -1.0, device=G.dev())
+        _lib.call('ssp_repack_dgrad_packed', wcl.data_ptr(), outp.data_ptr(), co, ci, cop, k, G.stream())
+        assert torch.equal(outp.cpu().reshape(ci, k * k, cop), refd)
 
 
 @pytest.mark.parametrize("pool", [0, 1])
