@@ -61,7 +61,9 @@ int ssp_bn_eval_prepare(int C, const float* gamma, const float* beta, const floa
 int ssp_bn_act_fwd(const float* x, int ldx, float* out, int ldo, const float* scale, const float* shift, int C, int B,
                    int H, int W, int pool, float slope, void* stream);
 /* g = gradient wrt the (pooled) activation; dx (may alias x) = gradient wrt the raw conv output;
- * partial: workspace of ssp_bn_bwd_blocks()*C*2 floats; c1, c2: C floats each. */
+ * partial: workspace of ssp_bn_bwd_blocks()*C*2 floats; c1, c2: C floats each (reduce -> fp64 finalize -> apply).
+ * partial == NULL selects the single-pass form: dgamma / dbeta must be ZERO on entry and 16-byte aligned, the reduce
+ * pass accumulates them with fp32 atomics and the apply pass reads them (no finalize launch; c1 / c2 unused). */
 int ssp_bn_bwd_blocks(void);
 int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
                    const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W, int pool,

@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int C, int B, int H,
-                                                                int W, int pool, float slope, float* partial) {
+                                                                int W, int pool, float slope, float* partial,
+                                                                float* acc_dgamma, float* acc_dbeta) {
   const int G = C >> 2;
   const int gpb = G < 256 ? G : 256;     // channel groups per block
   const int ppb = 256 / gpb;             // pixel lanes per block
@@ -224,9 +225,19 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
 #pragma unroll
       for (int k = 0; k < 4; ++k) { a[k] += u[k]; b[k] += v[k]; }
     }
-    float* dst = partial + ((int64_t)blockIdx.x * C + g4 * 4) * 2;
+    if (acc_dbeta != nullptr) {
+      // single-pass mode: the (<= 1024) workgroup sums go straight into the zero-initialised gradients with fp32
+      // hardware atomics; no finalize launch sits between this kernel and the apply pass
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { dst[2 * k] = a[k]; dst[2 * k + 1] = b[k]; }
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(acc_dbeta + g4 * 4 + k, a[k]);
+        atomicAdd(acc_dgamma + g4 * 4 + k, b[k]);
+      }
+    } else {
+      float* dst = partial + ((int64_t)blockIdx.x * C + g4 * 4) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { dst[2 * k] = a[k]; dst[2 * k + 1] = b[k]; }
+    }
   }
 }
 
@@ -263,8 +274,10 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* x, i
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ c1,
-                                                               const float* __restrict__ c2, int C, int B, int H, int W,
-                                                               int pool, float slope) {
+                                                               const float* __restrict__ c2, float kscale, int C, int B,
+                                                               int H, int W, int pool, float slope) {
+  // c1 / c2: per-channel mean(dy), mean(dy * xhat) (kscale = 1), or the SUMS dbeta / dgamma with kscale = 1 / N
+  // (single-pass mode; kscale = 0 in eval mode, where the statistics are constants)
   const int G = C >> 2;
   const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
   const int64_t total = (int64_t)B * Ho * Wo * G;
@@ -276,6 +289,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* x, i
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
     f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c), k2 = *reinterpret_cast<const f32x4*>(c2 + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { k1[k] *= kscale; k2[k] *= kscale; }
     if (!pool) {
       BwdItem it = bwd_item(x, ldx, g, ldg, po, 0, W, c, 0, slope, sc, sh, mu, is);
       f32x4 r;
@@ -381,15 +396,26 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
   if (nblk > ssp_bn_bwd_blocks_impl()) nblk = ssp_bn_bwd_blocks_impl();
   if (nblk < 1) nblk = 1;
   SspProfScope prof(SSP_PROF_BN_ACT, stream, 4.0 * C * (3.0 * (double)B * H * W + 2.0 * (double)npix));
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, ssp_cdiv(G, gpb)), dim3(256), 0, stream, x, ldx, g, ldg,
-                     scale, shift, mean, invstd, C, B, H, W, pool, slope, partial);
-  SSP_CHECK_LAUNCH("bn_act_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, nblk, C,
-                     1.0 / ((double)B * H * W), training, dgamma, dbeta, c1, c2);
-  SSP_CHECK_LAUNCH("bn_bwd_finalize");
   const int64_t total = npix * G;
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(total)), dim3(256), 0, stream, x, ldx, g, ldg, dx, lddx,
-                     scale, shift, mean, invstd, c1, c2, C, B, H, W, pool, slope);
+  if (partial == nullptr) {
+    // single pass: dgamma / dbeta zero-initialised by the caller, accumulated with atomics, read back by the apply pass
+    SSP_CHECK_ARG((((uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0, "bn_act_bwd: dgamma / dbeta must be 16-byte aligned");
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, ssp_cdiv(G, gpb)), dim3(256), 0, stream, x, ldx, g, ldg,
+                       scale, shift, mean, invstd, C, B, H, W, pool, slope, (float*)nullptr, dgamma, dbeta);
+    SSP_CHECK_LAUNCH("bn_act_bwd_reduce");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(total)), dim3(256), 0, stream, x, ldx, g, ldg, dx, lddx,
+                       scale, shift, mean, invstd, dbeta, dgamma, training ? (float)(1.0 / ((double)B * H * W)) : 0.f, C, B,
+                       H, W, pool, slope);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, ssp_cdiv(G, gpb)), dim3(256), 0, stream, x, ldx, g, ldg,
+                       scale, shift, mean, invstd, C, B, H, W, pool, slope, partial, (float*)nullptr, (float*)nullptr);
+    SSP_CHECK_LAUNCH("bn_act_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, nblk, C,
+                       1.0 / ((double)B * H * W), training, dgamma, dbeta, c1, c2);
+    SSP_CHECK_LAUNCH("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(total)), dim3(256), 0, stream, x, ldx, g, ldg, dx, lddx,
+                       scale, shift, mean, invstd, c1, c2, 1.f, C, B, H, W, pool, slope);
+  }
   SSP_CHECK_LAUNCH("bn_act_bwd_apply");
   return SSP_OK;
 }

@@ -535,11 +535,16 @@ class Plan(object):
                         dgam, dbet = gview(cs.bnm.weight), gview(cs.bnm.bias)
                         out_grads[id(cs.bnm.weight)], out_grads[id(cs.bnm.bias)] = dgam, dbet
                         dg_ptr, db_ptr = dgam.data_ptr(), dbet.data_ptr()
+                        # two-level reduction (per-workgroup partials -> fp64 finalize).  The single-pass form of
+                        # ssp_bn_act_bwd (atomics into the zeroed gradient, no finalize launch) measured 1.1 ms SLOWER
+                        # per step: 1024 workgroups hammering the same 2*C addresses serialise in the L2.
+                        partial = self.bn_partial.data_ptr()
                     else:
                         dg_ptr, db_ptr = v[6].data_ptr(), v[7].data_ptr()
+                        partial = self.bn_partial.data_ptr()
                     call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
                          v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
-                         1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, self.bn_partial.data_ptr(),
+                         1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, partial,
                          dg_ptr, db_ptr, v[4].data_ptr(), v[5].data_ptr(), st)
                     dy_ptr, dy_ld = cs.raw.data_ptr(), cs.ldraw
                     if cs.bn and cs.coutp != cs.cout:

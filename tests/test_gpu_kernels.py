@@ -219,6 +219,16 @@ def test_bn_act_fwd_bwd(C, B, H, W, pool):
               vec[7].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), G.stream())
     torch.cuda.synchronize()
     assert torch.equal(x2, dx)
+    # single-pass form (partial = NULL): zeroed dgamma / dbeta accumulated with atomics, no finalize launch, in place
+    x3 = xd.clone()
+    dgam, dbet = torch.zeros(C, device=G.dev()), torch.zeros(C, device=G.dev())
+    _lib.call('ssp_bn_act_bwd', x3.data_ptr(), C, gd.data_ptr(), C, x3.data_ptr(), C, vec[2].data_ptr(), vec[3].data_ptr(),
+              vec[0].data_ptr(), vec[1].data_ptr(), C, B, H, W, pool, 0.1, 1, None, dgam.data_ptr(), dbet.data_ptr(),
+              None, None, G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(x3, B, C, H, W).numpy(), x.grad.numpy()) < 2e-4
+    assert rel_err(dgam.cpu().numpy(), gamma.grad.numpy()) < 2e-4
+    assert rel_err(dbet.cpu().numpy(), beta.grad.numpy()) < 2e-4
 
 
 def test_reorg_route_maxpool_bit_exact(golden_dir):
