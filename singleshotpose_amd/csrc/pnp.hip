@@ -11,47 +11,18 @@
 //      diag(JtJ) scaling, stop when |step| / |params| < FLT_EPSILON), as CvLevMarq does for cvFindExtrinsicCameraParams2.
 // The rotation update uses the left-multiplicative exponential map instead of OpenCV's Rodrigues-vector chart; both
 // descend to the same least-squares minimum.
+//
+// Everything a thread touches is indexed at compile time (fully unrolled loops over 12 / 6 / 3), so the 12 x 12 normal
+// matrix, its Cholesky factor and the 6 x 6 LM system live in VGPRs: the first version kept them in dynamically indexed
+// arrays, i.e. in scratch memory, and took 2.1 ms for one pose.  The DLT null vector comes from inverse iteration on
+// the Cholesky-factored (lightly shifted) normal matrix instead of a full Jacobi eigen-decomposition (the smallest
+// eigen-pair is all that is used; the LM refinement that follows makes the result independent of how it was found),
+// the nearest rotation from the Newton iteration for the polar factor, the LM step from an unpivoted 6 x 6 Cholesky.
 #include "ssp_common.h"
 
 #define PNP_MAXN 16
 
-__device__ static void jacobi_eig(double* A, double* V, int n) {
-  // cyclic Jacobi on symmetric A (n x n, row-major, destroyed: eigenvalues end on the diagonal); V columns = eigenvectors
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int i = 0; i < n; ++i) {
-      diag += A[i * n + i] * A[i * n + i];
-      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
-    }
-    if (off <= 1e-34 * diag || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        double app = A[p * n + p], aqq = A[q * n + q];
-        double tau = (aqq - app) / (2.0 * apq);
-        double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq;
-          A[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - s * aqk;
-          A[q * n + k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq;
-          V[k * n + q] = s * vkp + c * vkq;
-        }
-      }
-  }
-}
+#define TRI(a, b) ((a) * ((a) + 1) / 2 + (b))   // packed lower triangle, a >= b
 
 __device__ static void so3_exp(const double* w, double* R) {
   double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -65,8 +36,10 @@ __device__ static void so3_exp(const double* w, double* R) {
   R[6] = -a * wy + b * wx * wz;         R[7] = a * wx + b * wy * wz;          R[8] = 1.0 - b * (wx * wx + wy * wy);
 }
 
-__device__ static void mat3_mul(const double* A, const double* B, double* C) {
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
 
@@ -78,24 +51,28 @@ __device__ static double rvec_norm2(const double* R) {
   return th * th;
 }
 
-__device__ static double reproj(const double* R, const double* t, const double* X, const double* uv, int N, double fx,
-                                double fy, double cx, double cy, double* JtJ, double* Jte) {
-  // returns |err|^2; when JtJ != nullptr also accumulates the 6x6 normal equations for (dw, dt)
-  if (JtJ) {
-    for (int i = 0; i < 36; ++i) JtJ[i] = 0.0;
+// |err|^2 of the pixel reprojection; WITH_J also accumulates the 6x6 normal equations (lower triangle, packed) for (dw, dt)
+template <bool WITH_J>
+__device__ __forceinline__ double reproj(const double* R, const double* t, const double* __restrict__ X,
+                                         const double* __restrict__ uv, int N, double fx, double fy, double cx,
+                                         double cy, double* JtJ, double* Jte) {
+  if (WITH_J) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) JtJ[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 6; ++i) Jte[i] = 0.0;
   }
   double e2 = 0.0;
   for (int i = 0; i < N; ++i) {
-    const double* P = X + 3 * i;
-    double rx = R[0] * P[0] + R[1] * P[1] + R[2] * P[2];
-    double ry = R[3] * P[0] + R[4] * P[1] + R[5] * P[2];
-    double rz = R[6] * P[0] + R[7] * P[1] + R[8] * P[2];
+    const double P0 = X[3 * i], P1 = X[3 * i + 1], P2 = X[3 * i + 2];
+    double rx = R[0] * P0 + R[1] * P1 + R[2] * P2;
+    double ry = R[3] * P0 + R[4] * P1 + R[5] * P2;
+    double rz = R[6] * P0 + R[7] * P1 + R[8] * P2;
     double x = rx + t[0], y = ry + t[1], z = rz + t[2];
     double iz = 1.0 / z;
     double eu = fx * x * iz + cx - uv[2 * i], ev = fy * y * iz + cy - uv[2 * i + 1];
     e2 += eu * eu + ev * ev;
-    if (JtJ) {
+    if (WITH_J) {
       // d(u,v)/d(x,y,z)
       double ux = fx * iz, uz = -fx * x * iz * iz, vy = fy * iz, vz = -fy * y * iz * iz;
       // d(x,y,z)/dw = -[R P]x ; d/dt = I
@@ -104,41 +81,58 @@ __device__ static double reproj(const double* R, const double* t, const double* 
       Jv[0] = -vy * rz + vz * ry; Jv[1] = -vz * rx;           Jv[2] = vy * rx;
       Ju[3] = ux; Ju[4] = 0.0; Ju[5] = uz;
       Jv[3] = 0.0; Jv[4] = vy; Jv[5] = vz;
+#pragma unroll
       for (int a = 0; a < 6; ++a) {
         Jte[a] += Ju[a] * eu + Jv[a] * ev;
-        for (int b = 0; b < 6; ++b) JtJ[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) JtJ[TRI(a, b)] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
       }
     }
   }
   return e2;
 }
 
-__device__ static bool solve6(const double* A_, const double* b_, double* x) {
-  double A[36], b[6];
-  for (int i = 0; i < 36; ++i) A[i] = A_[i];
-  for (int i = 0; i < 6; ++i) b[i] = b_[i];
-  for (int k = 0; k < 6; ++k) {
-    int piv = k;
-    double mx = fabs(A[k * 6 + k]);
-    for (int i = k + 1; i < 6; ++i)
-      if (fabs(A[i * 6 + k]) > mx) { mx = fabs(A[i * 6 + k]); piv = i; }
-    if (mx < 1e-300) return false;
-    if (piv != k) {
-      for (int j = 0; j < 6; ++j) { double tmp = A[k * 6 + j]; A[k * 6 + j] = A[piv * 6 + j]; A[piv * 6 + j] = tmp; }
-      double tmp = b[k]; b[k] = b[piv]; b[piv] = tmp;
-    }
-    for (int i = k + 1; i < 6; ++i) {
-      double f = A[i * 6 + k] / A[k * 6 + k];
-      for (int j = k; j < 6; ++j) A[i * 6 + j] -= f * A[k * 6 + j];
-      b[i] -= f * b[k];
+// in-place Cholesky of a packed lower-triangular SPD matrix (compile-time n); false when a pivot is not positive
+template <int n>
+__device__ __forceinline__ bool chol_packed(double* A) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double s = A[TRI(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= A[TRI(j, k)] * A[TRI(j, k)];
+    ok = ok && (s > 0.0);
+    const double g = sqrt(fmax(s, 1e-300));
+    const double ig = 1.0 / g;
+    A[TRI(j, j)] = g;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[TRI(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= A[TRI(i, k)] * A[TRI(j, k)];
+      A[TRI(i, j)] = v * ig;
     }
   }
-  for (int i = 5; i >= 0; --i) {
-    double s = b[i];
-    for (int j = i + 1; j < 6; ++j) s -= A[i * 6 + j] * x[j];
-    x[i] = s / A[i * 6 + i];
+  return ok;
+}
+
+// x <- (G G^T)^-1 x
+template <int n>
+__device__ __forceinline__ void chol_solve(const double* G, double* x) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= G[TRI(i, k)] * x[k];
+    x[i] = s / G[TRI(i, i)];
   }
-  return true;
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) s -= G[TRI(k, i)] * x[k];
+    x[i] = s / G[TRI(i, i)];
+  }
 }
 
 __global__ void __launch_bounds__(64) pnp_kernel(const double* __restrict__ pts3d, const double* __restrict__ pts2d,
@@ -151,85 +145,119 @@ __global__ void __launch_bounds__(64) pnp_kernel(const double* __restrict__ pts3
   const double* Km = Kmat + (int64_t)id * 9;
   const double fx = Km[0], fy = Km[4], cx = Km[2], cy = Km[5];
 
-  // ---- DLT ----
-  double L[144], V[144];
-  for (int i = 0; i < 144; ++i) L[i] = 0.0;
+  // ---- DLT: L = M^T M of the 2N x 12 system (packed lower triangle) ----
+  double L[78];
+#pragma unroll
+  for (int i = 0; i < 78; ++i) L[i] = 0.0;
   for (int i = 0; i < N; ++i) {
-    double xn = (uv[2 * i] - cx) / fx, yn = (uv[2 * i + 1] - cy) / fy;
-    double P[4] = {X[3 * i], X[3 * i + 1], X[3 * i + 2], 1.0};
+    const double xn = (uv[2 * i] - cx) / fx, yn = (uv[2 * i + 1] - cy) / fy;
+    const double P[4] = {X[3 * i], X[3 * i + 1], X[3 * i + 2], 1.0};
     double r0[12], r1[12];
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
       r0[k] = P[k]; r0[4 + k] = 0.0; r0[8 + k] = -xn * P[k];
       r1[k] = 0.0;  r1[4 + k] = P[k]; r1[8 + k] = -yn * P[k];
     }
+#pragma unroll
     for (int a = 0; a < 12; ++a)
-      for (int b = 0; b < 12; ++b) L[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+#pragma unroll
+      for (int b = 0; b <= a; ++b) L[TRI(a, b)] += r0[a] * r0[b] + r1[a] * r1[b];
   }
-  jacobi_eig(L, V, 12);
-  int imin = 0;
-  for (int i = 1; i < 12; ++i)
-    if (L[i * 12 + i] < L[imin * 12 + imin]) imin = i;
+  // smallest eigenvector by inverse iteration on L + mu I (mu ~ 1e-11 of the mean eigenvalue keeps the factorisation
+  // positive when the data are exact and L is singular to rounding; convergence factor (l_min + mu) / (l_2 + mu))
+  double tr = 0.0;
+#pragma unroll
+  for (int a = 0; a < 12; ++a) tr += L[TRI(a, a)];
+  const double mu = 1e-11 * tr / 12.0;
+#pragma unroll
+  for (int a = 0; a < 12; ++a) L[TRI(a, a)] += mu;
+  chol_packed<12>(L);
+  double v[12] = {0.3010, -0.5236, 0.1729, 0.4142, -0.2718, 0.1618, 0.5772, -0.3679, 0.2236, -0.1414, 0.6931, 0.3333};
+  for (int it = 0; it < 16; ++it) {
+    chol_solve<12>(L, v);
+    double nn = 0.0;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) nn += v[a] * v[a];
+    const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+    for (int a = 0; a < 12; ++a) v[a] *= inv;
+  }
   double RR[9], tt[3];
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) RR[r * 3 + c] = V[(r * 4 + c) * 12 + imin];
-    tt[r] = V[(r * 4 + 3) * 12 + imin];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) RR[r * 3 + c] = v[r * 4 + c];
+    tt[r] = v[r * 4 + 3];
   }
   double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +
                RR[2] * (RR[3] * RR[7] - RR[4] * RR[6]);
   if (det < 0.0) {
+#pragma unroll
     for (int i = 0; i < 9; ++i) RR[i] = -RR[i];
+#pragma unroll
     for (int i = 0; i < 3; ++i) tt[i] = -tt[i];
   }
   double sc = 0.0;
+#pragma unroll
   for (int i = 0; i < 9; ++i) sc += RR[i] * RR[i];
   sc = sqrt(sc);
-  // nearest rotation: R = RR (RR^T RR)^(-1/2)
-  double S[9], E[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) S[i * 3 + j] = RR[i] * RR[j] + RR[3 + i] * RR[3 + j] + RR[6 + i] * RR[6 + j];
-  jacobi_eig(S, E, 3);
-  double Sinv[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += E[i * 3 + k] * E[j * 3 + k] / sqrt(fmax(S[k * 3 + k], 1e-300));
-      Sinv[i * 3 + j] = s;
-    }
+  // nearest rotation = orthogonal polar factor of RR: Newton iteration Q <- (Q + Q^-T) / 2 from Q0 = RR * sqrt(3) / |RR|
   double R[9], t[3];
-  mat3_mul(RR, Sinv, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = RR[i] * (sqrt(3.0) / sc);
+  for (int it = 0; it < 12; ++it) {
+    double C[9];   // cofactor matrix = det * Q^-T
+    C[0] = R[4] * R[8] - R[5] * R[7]; C[1] = R[5] * R[6] - R[3] * R[8]; C[2] = R[3] * R[7] - R[4] * R[6];
+    C[3] = R[2] * R[7] - R[1] * R[8]; C[4] = R[0] * R[8] - R[2] * R[6]; C[5] = R[1] * R[6] - R[0] * R[7];
+    C[6] = R[1] * R[5] - R[2] * R[4]; C[7] = R[2] * R[3] - R[0] * R[5]; C[8] = R[0] * R[4] - R[1] * R[3];
+    const double d = R[0] * C[0] + R[1] * C[1] + R[2] * C[2];
+    const double id_ = 1.0 / d;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = 0.5 * (R[i] + C[i] * id_);
+  }
+#pragma unroll
   for (int i = 0; i < 3; ++i) t[i] = tt[i] * (sqrt(3.0) / sc);
 
   // ---- Levenberg-Marquardt refinement of the pixel reprojection error ----
-  double JtJ[36], Jte[6];
-  double err = reproj(R, t, X, uv, N, fx, fy, cx, cy, JtJ, Jte);
+  double JtJ[21], Jte[6];
+  double err = reproj<true>(R, t, X, uv, N, fx, fy, cx, cy, JtJ, Jte);
   int lambda_lg10 = -3, iters = 0;
   for (int guard = 0; guard < 200; ++guard) {
-    double A[36], d[6];
-    double lambda = pow(10.0, (double)lambda_lg10);
-    for (int i = 0; i < 36; ++i) A[i] = JtJ[i];
-    for (int i = 0; i < 6; ++i) A[i * 6 + i] *= 1.0 + lambda;
-    if (!solve6(A, Jte, d)) break;
+    double A[21], d[6];
+    const double lambda = pow(10.0, (double)lambda_lg10);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) A[i] = JtJ[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { A[TRI(i, i)] *= 1.0 + lambda; d[i] = Jte[i]; }
+    if (!chol_packed<6>(A)) break;
+    chol_solve<6>(A, d);
     double w[3] = {-d[0], -d[1], -d[2]}, dR[9], Rn[9], tn[3];
     so3_exp(w, dR);
     mat3_mul(dR, R, Rn);
+#pragma unroll
     for (int i = 0; i < 3; ++i) tn[i] = t[i] - d[3 + i];
-    double err_n = reproj(Rn, tn, X, uv, N, fx, fy, cx, cy, nullptr, nullptr);
-    if (err_n > err) {
+    double err_n = reproj<false>(Rn, tn, X, uv, N, fx, fy, cx, cy, nullptr, nullptr);
+    if (!(err_n <= err)) {
       if (++lambda_lg10 > 16) break;
       continue;
     }
     lambda_lg10 = max(lambda_lg10 - 1, -16);
     double pn = sqrt(rvec_norm2(R) + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
     double dn = 0.0;
+#pragma unroll
     for (int i = 0; i < 6; ++i) dn += d[i] * d[i];
     dn = sqrt(dn);
+#pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = tn[i];
     if (++iters >= max_iter || dn < 1.1920928955078125e-07 * pn) break;
-    err = reproj(R, t, X, uv, N, fx, fy, cx, cy, JtJ, Jte);
+    err = reproj<true>(R, t, X, uv, N, fx, fy, cx, cy, JtJ, Jte);
   }
   double* o = Rt + (int64_t)id * 12;
+#pragma unroll
   for (int i = 0; i < 9; ++i) o[i] = R[i];
+#pragma unroll
   for (int i = 0; i < 3; ++i) o[9 + i] = t[i];
 }
 
