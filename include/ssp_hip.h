@@ -37,6 +37,12 @@ int ssp_set_option(const char* name, int value);
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
                  int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* workspace,
                  int64_t workspace_floats, void* stream);
+/* eval-mode block in one launch (darknet.py:154-167 with BatchNorm in inference mode):
+ * out[p][co] = leaky(scale[co] * conv(in, wt)[p][co] + shift[co], slope); scale / shift from ssp_bn_eval_prepare
+ * (either may be NULL = 1 / 0), slope = 1 for a linear block.  Same shapes, workspace and limits as ssp_conv_fwd. */
+int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const float* scale, const float* shift,
+                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R,
+                        float* workspace, int64_t workspace_floats, void* stream);
 int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R);
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R);
 

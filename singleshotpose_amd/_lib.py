@@ -27,6 +27,7 @@ _SIGS = {
     "ssp_abi_version": [],
     "ssp_set_option": [c_char_p, I],
     "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_fwd_affine": [P, P, P, P, P, F, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_stats_tile_m": [I, I, I, I, I, I],
     "ssp_conv_workspace_floats": [I, I, I, I, I, I],
     "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],

@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) 
 // (16 per slab) x one of 16 row lanes; Welford per thread, Chan-combine of the 16 row lanes through LDS.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
                                                             const float* __restrict__ bias, float* stats, int M,
-                                                            int Cout, int tile_m, int accumulate) {
+                                                            int Cout, int tile_m, int accumulate,
+                                                            const float* __restrict__ escale, float act_slope) {
   const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
   const int c = blockIdx.y * 64 + gl * 4;
   const int m0 = blockIdx.x * tile_m, m1 = min(M, m0 + tile_m);
@@ -298,6 +299,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   if (cok && bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 e4 = {1.f, 1.f, 1.f, 1.f};
+  if (cok && escale != nullptr) e4 = *reinterpret_cast<const f32x4*>(escale + c);
   if (cok) {
     for (int m = m0 + pp; m < m1; m += 16) {
       f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
@@ -314,7 +317,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         m2[k] += d * (v[k] - mean[k]);
       }
       float* dst = out + (int64_t)m * ldout + c;
-      f32x4 o = {v[0] + b4[0], v[1] + b4[1], v[2] + b4[2], v[3] + b4[3]};
+      f32x4 o = {v[0] * e4[0] + b4[0], v[1] * e4[1] + b4[1], v[2] * e4[2] + b4[2], v[3] * e4[3] + b4[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : o[k] * act_slope;
       if (accumulate) {
         const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
         o[0] += prev[0]; o[1] += prev[1]; o[2] += prev[2]; o[3] += prev[3];
@@ -423,7 +428,7 @@ int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R) {
 
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
-                          int64_t ws_floats, int prof_kind, hipStream_t stream) {
+                          int64_t ws_floats, int prof_kind, hipStream_t stream, const float* escale, float act_slope) {
   SSP_CHECK_ARG(R == 1 || R == 3, "conv: only 1x1 and 3x3 filters are supported (got %d)", R);
   SSP_CHECK_ARG(Cin % 4 == 0 && Cin > 0, "conv: Cin must be a positive multiple of 4 (got %d)", Cin);
   SSP_CHECK_ARG(ldin % 4 == 0 && ldin >= Cin, "conv: ldin must be a multiple of 4 and >= Cin");
@@ -431,7 +436,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   SSP_CHECK_ARG((int64_t)B * H * W < (1ll << 31), "conv: too many pixels");
   SSP_CHECK_ARG((((uintptr_t)in) & 15) == 0 && (((uintptr_t)wt) & 15) == 0, "conv: in/wt must be 16-byte aligned");
   ConvArgs a;
-  a.in = in; a.wt = wt; a.out = out; a.bias = bias; a.stats = stats;
+  a.in = in; a.wt = wt; a.out = out; a.bias = bias; a.stats = stats; a.escale = escale; a.act_slope = act_slope;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
@@ -493,7 +498,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   if (rc != SSP_OK) return rc;
   if (pl.ksplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
-                       bias, stats, a.M, Cout, pl.bm, accumulate);
+                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope);
     SSP_CHECK_LAUNCH("splitk_reduce");
   }
   return SSP_OK;

@@ -8,7 +8,9 @@ struct ConvArgs {
   const float* in;
   const float* wt;
   float* out;
-  const float* bias;  // [Cout] or nullptr (added in the epilogue; the linear head conv)
+  const float* bias;  // [Cout] or nullptr (added in the epilogue; the linear head conv, or the BN shift in eval mode)
+  const float* escale; // [Cout] or nullptr: per-channel factor applied before the bias (eval-mode BatchNorm folded in)
+  float act_slope;    // leaky-ReLU slope applied last (1 = no activation)
   float* stats;       // [ntile_m][Cout][2] = per-M-tile (mean, M2) of the raw output, or nullptr
   int H, W, Cin, Cout, ldin, ldout, R, M;
   int accumulate;     // out += result (second consumer of a routed activation in dgrad)
@@ -63,6 +65,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
       const int n = n0 + wn * WTN + j * 32 + li;
       const bool n_ok = n < p.Cout;
       const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+      const float esc = (p.escale != nullptr && n_ok) ? p.escale[n] : 1.f;
       float cnt = 0.f, sum = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -70,7 +73,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
         for (int r = 0; r < 16; ++r) {
           int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           int m = m0 + row;
-          float v = acc[i][j][r] + bias;
+          float v = acc[i][j][r] * esc + bias;
+          v = v > 0.f ? v : v * p.act_slope;
           if (m < p.M && n_ok) {
             float* o = p.out + (int64_t)m * p.ldout + n;
             if constexpr (ACCUM) v += *o;

@@ -12,7 +12,8 @@ int ssp_conv_tile_m(int M, int Cin, int Cout, int R);
 int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R);
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
-                          int64_t ws_floats, int prof_kind, hipStream_t stream);
+                          int64_t ws_floats, int prof_kind, hipStream_t stream, const float* escale = nullptr,
+                          float act_slope = 1.f);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
@@ -128,6 +129,12 @@ int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias
                  int64_t workspace_floats, void* stream) {
   return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate, workspace,
                                workspace_floats, SSP_PROF_CONV_FWD, (hipStream_t)stream);
+}
+int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const float* scale, const float* shift,
+                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R,
+                        float* workspace, int64_t workspace_floats, void* stream) {
+  return ssp_conv_igemm_launch(in, wt, out, shift, nullptr, B, H, W, Cin, Cout, ldin, ldout, R, 0, workspace,
+                               workspace_floats, SSP_PROF_CONV_FWD, (hipStream_t)stream, scale, slope);
 }
 int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R) {
   return ssp_conv_tile_m(B * H * W, Cin, Cout, R);

@@ -10,6 +10,7 @@ forward never calls them.  All device work goes through libssp_hip.so (engine.Pl
 fallback: a CPU tensor or a missing library raises.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -78,6 +79,9 @@ class Darknet(nn.Module):
         self.iter = 0
         self._plans = collections.OrderedDict()
         self._max_plans = 32
+        # eval forward as one captured hipGraph replay (Plan.forward_graph).  Opt-in: measured no gain on MI355X - the
+        # ~12 us between dependent launches is GPU-side, not host launch cost (B=1, 672x672: 1.80 ms both ways)
+        self.graph_inference = os.environ.get('SSP_GRAPH_INFERENCE', '0') == '1'
         self._plan_mem_frac = 0.5
 
     # ---- network construction: same module tree as darknet.py:135-249 ----
@@ -241,6 +245,8 @@ class Darknet(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad:
             return _DarknetFn.apply(plan, self.training, x, *params)
+        if self.graph_inference and not self.training:
+            return plan.forward_graph(x)      # eval: the whole launch chain as one hipGraph replay
         return plan.forward(x, self.training)
 
     def print_network(self):

@@ -250,6 +250,7 @@ class Plan(object):
         self.ws_floats = max([1] + [max(cs.ws_fwd, cs.ws_dgrad) for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
         self.wversion = {}
+        self.bnversion = {}
         self.generation = 0
         # flat gradient buffer layout, in backward (reverse layer) order so that all-reduce buckets close early:
         # per conv block: weight | bias  or  weight | bn.weight | bn.bias   (each 16-byte aligned)
@@ -274,6 +275,8 @@ class Plan(object):
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
         self.consumed = False
+        self._graph = self._graph_key = self._x_static = self._y_static = None
+        self._graph_failed = False
 
     # ------------------------------------------------------------------ per-shape tile / split selection
     def _autotune(self):
@@ -292,8 +295,10 @@ class Plan(object):
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
             return
-        max_ws = max(3 * cs.M * max(cs.coutp, cs.cinp) for cs in elig if cs.M * max(cs.coutp, cs.cinp) <= (1 << 25)) \
-            if any(cs.M * max(cs.coutp, cs.cinp) <= (1 << 25) for cs in elig) else 1
+        def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x3 mid, none big)
+            mc = cs.M * max(cs.coutp, cs.cinp)
+            return 9 * mc if mc <= (1 << 21) else (3 * mc if mc <= (1 << 25) else 1)
+        max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
         stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32)
         gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32)
@@ -302,7 +307,10 @@ class Plan(object):
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
                 return _TUNE_CACHE[key]
             best, best_t = 0, None
-            for code in cands:
+            # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
+            # deep K splits put every CU on the weight stream
+            deep = (12864, 12894, 6464, 6494) if mn <= (1 << 21) else ()
+            for code in cands + deep:
                 if (code // 10) % 10 > 1 and mn > (1 << 25):
                     continue
                 call('ssp_set_option', b'igemm_plan', code)
@@ -343,7 +351,7 @@ class Plan(object):
             _tune_cache_save()
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training, need_grad=False):
+    def forward(self, x, training, need_grad=False, inline_repack=False):
         B, H, W = self.B, self.H, self.W
         st = torch.cuda.current_stream().cuda_stream
         call = _lib.call
@@ -368,7 +376,12 @@ class Plan(object):
                 if cs.packed:
                     continue
                 key = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
-                if training or self.wversion.get(cs.ind) != key:
+                if inline_repack:
+                    # graph capture: the repack is part of the captured chain (stays on this stream, runs every replay)
+                    call('ssp_repack_fwd', wt.detach().contiguous().data_ptr(), _ptr(self.wpack, cs.woff), cs.cout,
+                         cs.cin, cs.cinp, cs.k, st)
+                    self.wversion.pop(cs.ind, None)
+                elif training or self.wversion.get(cs.ind) != key:
                     stale.append((cs, key))
         wait_for = {}
         if stale or need_grad:
@@ -413,22 +426,36 @@ class Plan(object):
                     waited.add(id(ev))
                 bias = cs.conv.bias.data_ptr() if cs.conv.bias is not None else None
                 use_stats = cs.bn and training
-                call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
-                call('ssp_conv_fwd', cs.inp.ptr, cs.conv.weight.data_ptr() if cs.packed else _ptr(self.wpack, cs.woff),
-                     cs.raw.data_ptr(), bias, cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout,
-                     cs.inp.ld, cs.ldraw, cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
                 v = cs.vec
-                if cs.bn:
+                if cs.bn and not training:
+                    # inference-mode BatchNorm is a per-channel affine map of constants: recomputed only when one of
+                    # its four tensors changed (in-place updates bump _version; load_weights / fused SGD bump the epoch)
                     bn = cs.bnm
-                    if training:
-                        call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
-                             bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                             bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
-                             v[2].data_ptr(), v[3].data_ptr(), st)
-                    else:
+                    bkey = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean,
+                                                                     bn.running_var)) + (_WEIGHTS_EPOCH[0],)
+                    if inline_repack or self.bnversion.get(cs.ind) != bkey:
                         call('ssp_bn_eval_prepare', cs.cout, bn.weight.data_ptr(), bn.bias.data_ptr(),
                              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS, v[0].data_ptr(),
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
+                        self.bnversion[cs.ind] = None if inline_repack else bkey
+                call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
+                wptr = cs.conv.weight.data_ptr() if cs.packed else _ptr(self.wpack, cs.woff)
+                if not training and not need_grad and cs.needs_act and not cs.pool and cs.coutp == cs.cout:
+                    # inference, un-pooled block: BatchNorm affine + leaky folded into the conv epilogue - one launch,
+                    # no raw-output round trip (backward needs the raw output, so training / autograd keep two steps)
+                    call('ssp_conv_fwd_affine', cs.inp.ptr, wptr, cs.out.ptr, v[2].data_ptr() if cs.bn else None,
+                         v[3].data_ptr() if cs.bn else bias, cs.slope, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld,
+                         cs.out.ld, cs.k, self.ws.data_ptr(), self.ws_floats, st)
+                    continue
+                call('ssp_conv_fwd', cs.inp.ptr, wptr, cs.raw.data_ptr(), bias,
+                     cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
+                     cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
+                if cs.bn and training:
+                    bn = cs.bnm
+                    call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
+                         bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                         bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
+                         v[2].data_ptr(), v[3].data_ptr(), st)
                 if cs.needs_act:
                     call('ssp_bn_act_fwd', cs.raw.data_ptr(), cs.ldraw, cs.out.ptr, cs.out.ld, v[2].data_ptr(),
                          v[3].data_ptr(), cs.coutp, B, cs.H, cs.W, 1 if cs.pool else 0, cs.slope, st)
@@ -451,6 +478,46 @@ class Plan(object):
         self.was_training = training
         self.generation += 1
         return y
+
+    # ------------------------------------------------------------------ inference as one hipGraph
+    def _graph_tensors(self):
+        ts = []
+        for cs in self.convs.values():
+            ts.append(cs.conv.weight)
+            if cs.conv.bias is not None:
+                ts.append(cs.conv.bias)
+            if cs.bn:
+                ts += [cs.bnm.weight, cs.bnm.bias, cs.bnm.running_mean, cs.bnm.running_var]
+        return ts
+
+    def forward_graph(self, x):
+        """Eval-mode forward replayed from a captured hipGraph: the ~75 launches of a forward pass are launch-bound at
+        small batch (valid.py runs B = 1: 1.8 ms eager for 0.6 ms of kernels).  The kernels read parameters and BN
+        running statistics from their own memory, so in-place weight updates need no re-capture; a parameter that moved
+        (new data_ptr), another input dtype, or a non-contiguous first-layer filter does."""
+        if self._graph_failed:
+            return self.forward(x, False)
+        key = (x.dtype,) + tuple((t.data_ptr(), tuple(t.stride())) for t in self._graph_tensors())
+        if self._graph is None or self._graph_key != key:
+            try:
+                self._x_static = torch.empty_like(x)
+                self._x_static.copy_(x)
+                self.forward(self._x_static, False, inline_repack=True)      # eager warm-up (lazy per-kernel set-up)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    y = self.forward(self._x_static, False, inline_repack=True)
+                self._graph, self._y_static, self._graph_key = g, y, key
+            except Exception as e:      # capture unsupported in this runtime: keep the eager HIP launches
+                import warnings
+                warnings.warn("hipGraph capture of the inference chain failed (%s); using eager launches" % (e,))
+                self._graph, self._graph_failed = None, True
+                torch.cuda.synchronize(self.device)
+                return self.forward(x, False)
+        self._x_static.copy_(x)
+        self._graph.replay()
+        self.consumed = True          # no backward on a graph replay
+        return self._y_static.clone()
 
     # ------------------------------------------------------------------ backward
     def _grad_buf(self, ind, like):

@@ -329,3 +329,49 @@ def test_filters_are_channels_last_and_used_in_place():
     for c, g1 in zip(convs, grads1):
         assert c.weight.grad.shape == g1.shape
         assert rel_err(c.weight.grad.cpu().numpy(), g1.cpu().numpy()) < 2e-5      # fp32 atomics: order differs
+
+
+def test_graph_inference_matches_eager_and_tracks_weight_updates():
+    """Eval forward replayed from a captured hipGraph: bit-identical to the eager launch chain, sees in-place parameter
+    and running-statistics updates without re-capture, re-captures when a parameter tensor moves."""
+    model, _ = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 21)
+    model.eval()
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.rand(2, 3, 96, 96, generator=g).cuda() for _ in range(3)]
+    with torch.no_grad():
+        model.graph_inference = False
+        eager = [model(x).clone() for x in xs]
+        model.graph_inference = True
+        plan = list(model._plans.values())[0]
+        got = [model(x) for x in xs]
+        assert plan._graph is not None and not plan._graph_failed
+        for a, b in zip(eager, got):
+            assert torch.equal(a, b)
+        assert got[0].data_ptr() != got[1].data_ptr()          # fresh output tensors, not the graph's static buffer
+        graph0 = plan._graph
+        # in-place updates (what load_weights / an optimizer step do): same graph, new numbers
+        convs = [m for m in model.modules() if isinstance(m, torch.nn.Conv2d)]
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        convs[0].weight.data.mul_(1.1)
+        convs[2].weight.data.add_(0.01)
+        bns[1].running_mean.add_(0.05)
+        y_graph = model(xs[0])
+        assert plan._graph is graph0 and not torch.equal(y_graph, eager[0])
+        model.graph_inference = False
+        assert torch.equal(model(xs[0]), y_graph)
+        # a parameter that moved to new storage: re-capture
+        model.graph_inference = True
+        convs[1].weight.data = convs[1].weight.data.clone(memory_format=torch.preserve_format)
+        y2 = model(xs[0])
+        assert plan._graph is not graph0 and torch.equal(y2, y_graph)
+        # uint8 input goes through its own capture
+        img = (xs[0].permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
+        yu = model(img)
+        model.graph_inference = False
+        assert torch.equal(model(img), yu)
+    # training-mode and autograd forwards never take the graph path
+    model.graph_inference = True
+    model.train()
+    y = model(xs[0])
+    y.sum().backward()
+    assert convs[0].weight.grad is not None

@@ -314,3 +314,39 @@ def test_u8_image_to_nhwc_bit_exact(B, H, W, C, Cp, ld):
     got = dst.cpu().numpy()
     assert np.array_equal(got[:, :C], want)
     assert np.all(got[:, C:Cp] == 0.0) and np.all(got[:, Cp:] == -7.0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,R,plan,slope,with_scale", [
+    (2, 13, 13, 64, 128, 3, 0, 0.1, True),        # LDS-direct 128x128 tile, epilogue path
+    (3, 10, 14, 128, 256, 3, 12834, 0.1, True),   # forced split-K x3: affine + leaky applied by the partial-sum pass
+    (2, 9, 9, 64, 20, 1, 0, 1.0, False),          # linear head: shift only (bias), 256x32 tile
+    (1, 12, 12, 3, 32, 3, 0, 0.1, True),          # first layer (4-channel register-staged kernel)
+])
+def test_conv_fwd_affine_eval_block(B, H, W, Cin, Cout, R, plan, slope, with_scale):
+    """ssp_conv_fwd_affine = the whole inference-mode block (darknet.py:154-167): leaky(scale * conv + shift)."""
+    G, _lib = _imports()
+    rs = np.random.RandomState(Cin + Cout + R)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, R, R)) / np.sqrt(Cin * R * R)).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
+    y = F.conv2d(x, w, None, padding=R // 2)
+    if with_scale:
+        y = y * scale.view(1, -1, 1, 1)
+    ref = F.leaky_relu(y + shift.view(1, -1, 1, 1), slope) if slope != 1.0 else y + shift.view(1, -1, 1, 1)
+    cinp = (Cin + 3) // 4 * 4
+    xp = torch.zeros(B, cinp, H, W)
+    xp[:, :Cin] = x
+    xd, wd = G.to_nhwc(xp), G.pack_fwd(w, cinp)
+    out = torch.full((B * H * W, Cout), float('nan'), dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_set_option', b'igemm_plan', plan)
+    try:
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R))
+        ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+        sd, hd = scale.to(G.dev()), shift.to(G.dev())
+        _lib.call('ssp_conv_fwd_affine', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), sd.data_ptr() if with_scale else None,
+                  hd.data_ptr(), slope, B, H, W, cinp, Cout, cinp, Cout, R, ws.data_ptr(), wsn, G.stream())
+        torch.cuda.synchronize()
+    finally:
+        _lib.call('ssp_set_option', b'igemm_plan', 0)
+    assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
