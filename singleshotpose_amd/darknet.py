@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from .cfg import (load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, resolve_layers, save_conv, save_conv_bn,
                   save_fc)
-from .engine import Plan, _DarknetFn
+from .engine import Plan, _DarknetFn, weights_changed
 from .region_loss import RegionLoss, RegionLossMulti
 
 
@@ -277,8 +277,13 @@ class Darknet(nn.Module):
                     start = load_conv(buf, start, model[0])
             elif t == 'connected':
                 start = load_fc(buf, start, self.models[ind])
+        # .data.copy_ (cfg.py's loaders, as the reference's) does not bump the autograd version counters the plans key
+        # their cached filter packs / inference-mode BN constants on: invalidate them explicitly.  (Code that mutates
+        # parameters through `.data` itself should call singleshotpose_amd.engine.weights_changed() too.)
+        weights_changed()
         for plan in self._plans.values():
-            plan.wversion.clear()   # .data.copy_ does not bump the autograd version counter
+            plan.wversion.clear()
+            plan.bnversion.clear()
 
     def load_weights(self, weightfile):
         self._load_blocks(self._read_weights(weightfile), len(self.blocks))

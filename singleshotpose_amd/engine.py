@@ -228,26 +228,28 @@ class Plan(object):
                 prev = self.acts[ind]
             else:  # region / cost: not executed in forward (darknet.py:119-127)
                 self.acts[ind] = prev
-        self.wpack = torch.empty(max(wsz, 1), **f32)
-        self.dpack = torch.empty(max(dsz, 1), **f32)
-        self.gpack = torch.empty(max(wsz, 1), **f32)   # packed filter gradients (zeroed each backward)
+        # Filter staging buffers are allocated when first needed: channels-last parameters are used in place, so only the
+        # padded first layer (or a filter a caller replaced by a plain contiguous tensor) gets a forward / gradient
+        # staging copy, and the data-gradient operands (202 MB) exist only in plans that run a backward.
+        self._dpack_floats = max(dsz, 1)
+        self._dpack = None
+        self._dgrad_tuned = False
         self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
-        if device.type == 'cuda' and os.environ.get('SSP_AUTOTUNE', '1') != '0':
-            self._autotune()
+        self._tune = device.type == 'cuda' and os.environ.get('SSP_AUTOTUNE', '1') != '0'
+        if self._tune:
+            self._autotune('fwd')
         # statistics / split-K workspaces follow the (tuned or heuristic) plan of each launch
         for cs in self.convs.values():
             M = cs.M
             _lib.call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
             cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
             cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
-            _lib.call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
-            cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k)
             cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
             if cs.bn:
                 cs.stats = torch.empty(cs.ntile * cs.cout * 2, **f32)
         _lib.call('ssp_set_option', b'igemm_plan', 0)
         # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
-        self.ws_floats = max([1] + [max(cs.ws_fwd, cs.ws_dgrad) for cs in self.convs.values()])
+        self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
         self.wversion = {}
         self.bnversion = {}
@@ -278,8 +280,49 @@ class Plan(object):
         self._graph = self._graph_key = self._x_static = self._y_static = None
         self._graph_failed = False
 
+    # ------------------------------------------------------------------ lazily allocated filter staging
+    def _wbuf(self, cs):
+        if getattr(cs, 'wbuf', None) is None:
+            cs.wbuf = torch.empty(cs.cout * cs.k * cs.k * cs.cinp, dtype=torch.float32, device=self.device)
+        return cs.wbuf
+
+    def _gbuf(self, cs):
+        if getattr(cs, 'gbuf', None) is None:
+            cs.gbuf = torch.empty(cs.cout * cs.k * cs.k * cs.cinp, dtype=torch.float32, device=self.device)
+        return cs.gbuf
+
+    def _prepare_backward(self):
+        """First forward that will be followed by a backward: data-gradient operand buffer, dgrad plan tuning, and the
+        split-K workspace those plans need."""
+        if self._dpack is None:
+            self._dpack = torch.empty(self._dpack_floats, dtype=torch.float32, device=self.device)
+        if not self._dgrad_tuned:
+            self._dgrad_tuned = True
+            if self._tune:
+                self._autotune('dgrad')
+            need = 1
+            for cs in self.convs.values():
+                _lib.call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
+                cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
+                                                            cs.cin, cs.k)
+                need = max(need, cs.ws_dgrad)
+            _lib.call('ssp_set_option', b'igemm_plan', 0)
+            if need > self.ws_floats:
+                torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
+                self.ws_floats = need
+                self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+
+    def _repack_dgrad(self, cs, stream):
+        src = cs.conv.weight.detach()
+        if not cs.packed:
+            with torch.cuda.stream(stream):
+                src = src.contiguous()       # the plain-layout kernel reads (Cout,Cin,kh,kw) order
+                src.record_stream(stream)
+        _lib.call('ssp_repack_dgrad_packed' if cs.packed else 'ssp_repack_dgrad', src.data_ptr(),
+                  _ptr(self._dpack, cs.doff), cs.cout, cs.cin, cs.coutp, cs.k, stream.cuda_stream)
+
     # ------------------------------------------------------------------ per-shape tile / split selection
-    def _autotune(self):
+    def _autotune(self, which):
         """Times the candidate igemm plans (tile rows x split-K x LDS ring depth) of every eligible conv launch of this
         input shape on the real buffers and keeps the fastest (per-shape tile selection).
         The library's shape heuristic is within ~5-15 % of the best choice on some layers; which plan wins depends on
@@ -300,8 +343,8 @@ class Plan(object):
             return 9 * mc if mc <= (1 << 21) else (3 * mc if mc <= (1 << 25) else 1)
         max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
-        stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32)
-        gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32)
+        stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32) if which == 'fwd' else None
+        gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32) if which == 'dgrad' else None
 
         def best_of(launch, cout, mn, key):
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
@@ -333,14 +376,16 @@ class Plan(object):
             return best
 
         for cs in elig:
-            if cs.cout > 64:
-                cs.plan_fwd = best_of(lambda: call('ssp_conv_fwd', cs.inp.ptr, _ptr(self.wpack, cs.woff), cs.raw.data_ptr(),
+            if which == 'fwd' and cs.cout > 64:
+                # operand contents are irrelevant for timing: a channels-last-sized parameter stands in for itself
+                wop = cs.conv.weight if cs.cinp == cs.cin else self._wbuf(cs)
+                cs.plan_fwd = best_of(lambda: call('ssp_conv_fwd', cs.inp.ptr, wop.data_ptr(), cs.raw.data_ptr(),
                                                    None, stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp,
                                                    cs.cout, cs.inp.ld, cs.ldraw, cs.k, 0, ws.data_ptr(), max_ws, st),
                                       cs.cout, cs.M * cs.coutp,
                                       ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn)))
-            if not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
-                cs.plan_dgrad = best_of(lambda: call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self.dpack, cs.doff),
+            if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
+                cs.plan_dgrad = best_of(lambda: call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self._dpack, cs.doff),
                                                      gscratch.data_ptr(), B, cs.H, cs.W, cs.coutp, cs.cin, cs.ldraw,
                                                      cs.inp.ld, cs.k, 0, ws.data_ptr(), max_ws, st),
                                         cs.cin, cs.M * cs.cinp,
@@ -378,11 +423,13 @@ class Plan(object):
                 key = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
                 if inline_repack:
                     # graph capture: the repack is part of the captured chain (stays on this stream, runs every replay)
-                    call('ssp_repack_fwd', wt.detach().contiguous().data_ptr(), _ptr(self.wpack, cs.woff), cs.cout,
+                    call('ssp_repack_fwd', wt.detach().contiguous().data_ptr(), self._wbuf(cs).data_ptr(), cs.cout,
                          cs.cin, cs.cinp, cs.k, st)
                     self.wversion.pop(cs.ind, None)
                 elif training or self.wversion.get(cs.ind) != key:
                     stale.append((cs, key))
+        if need_grad:
+            self._prepare_backward()
         wait_for = {}
         if stale or need_grad:
             if self.side_stream is None:
@@ -394,7 +441,7 @@ class Plan(object):
                     with torch.cuda.stream(side):
                         src = cs.conv.weight.detach().contiguous()      # the repack kernels read (Cout,Cin,kh,kw) order
                         src.record_stream(side)
-                    call('ssp_repack_fwd', src.data_ptr(), _ptr(self.wpack, cs.woff), cs.cout, cs.cin,
+                    call('ssp_repack_fwd', src.data_ptr(), self._wbuf(cs).data_ptr(), cs.cout, cs.cin,
                          cs.cinp, cs.k, side.cuda_stream)
                     self.wversion[cs.ind] = key
                 if group:
@@ -405,13 +452,7 @@ class Plan(object):
             for ind in sorted(self.convs.keys(), reverse=True):
                 cs = self.convs[ind]
                 if not cs.first:
-                    src = cs.conv.weight.detach()
-                    if not cs.packed:
-                        with torch.cuda.stream(side):
-                            src = src.contiguous()
-                            src.record_stream(side)
-                    call('ssp_repack_dgrad_packed' if cs.packed else 'ssp_repack_dgrad', src.data_ptr(),
-                         _ptr(self.dpack, cs.doff), cs.cout, cs.cin, cs.coutp, cs.k, side.cuda_stream)
+                    self._repack_dgrad(cs, side)
             self.dgrad_ready = side.record_event()
         else:
             self.dgrad_ready = None
@@ -439,7 +480,7 @@ class Plan(object):
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
                         self.bnversion[cs.ind] = None if inline_repack else bkey
                 call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
-                wptr = cs.conv.weight.data_ptr() if cs.packed else _ptr(self.wpack, cs.woff)
+                wptr = cs.conv.weight.data_ptr() if cs.packed else self._wbuf(cs).data_ptr()
                 if not training and not need_grad and cs.needs_act and not cs.pool and cs.coutp == cs.cout:
                     # inference, un-pooled block: BatchNorm affine + leaky folded into the conv epilogue - one launch,
                     # no raw-output round trip (backward needs the raw output, so training / autograd keep two steps)
@@ -545,9 +586,9 @@ class Plan(object):
         if o.ld > o.C:
             raise NotImplementedError("network output channels must be a multiple of 4")
         written.add(self.last)
-        for cs in self.convs.values():          # packed-gradient staging of the parameters that are not channels-last
+        for cs in self.convs.values():          # gradient staging of the parameters that are not channels-last
             if not cs.packed:
-                self.gpack[cs.woff:cs.woff + cs.cout * cs.k * cs.k * cs.cinp].zero_()
+                self._gbuf(cs).zero_()
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
         if self.side_stream is None:
@@ -558,11 +599,11 @@ class Plan(object):
         if self.dgrad_ready is not None:
             main.wait_event(self.dgrad_ready)       # dgrad filter repacks were queued during forward
         else:
+            self._prepare_backward()
             for ind in sorted(self.convs.keys(), reverse=True):   # forward ran without grad bookkeeping: repack now
                 cs = self.convs[ind]
                 if not cs.first:
-                    call('ssp_repack_dgrad', cs.conv.weight.data_ptr(), _ptr(self.dpack, cs.doff), cs.cout, cs.cin,
-                         cs.coutp, cs.k, st)
+                    self._repack_dgrad(cs, main)
         out_grads = {}
         training = self.was_training
         # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
@@ -630,9 +671,9 @@ class Plan(object):
                     call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
                          cs.inp.ld, cs.k, st2)
                 else:
-                    call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, _ptr(self.gpack, cs.woff), B, cs.H, cs.W, cs.cinp,
+                    call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, self._gbuf(cs).data_ptr(), B, cs.H, cs.W, cs.cinp,
                          cs.cout, dy_ld, cs.inp.ld, cs.k, st2)
-                    call('ssp_unpack_grad', _ptr(self.gpack, cs.woff), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
+                    call('ssp_unpack_grad', self._gbuf(cs).data_ptr(), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
                 out_grads[id(cs.conv.weight)] = gw
                 if self.reducer is not None:
                     with torch.cuda.stream(side):   # the all-reduce of a finished bucket is ordered after its wgrads
@@ -641,7 +682,7 @@ class Plan(object):
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
                     call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
-                    call('ssp_conv_dgrad', dy_ptr, _ptr(self.dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
+                    call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
                          cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, self.ws.data_ptr(), self.ws_floats, st)
                     written.add(src)
             elif t == 'maxpool':

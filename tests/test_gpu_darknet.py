@@ -375,3 +375,27 @@ def test_graph_inference_matches_eager_and_tracks_weight_updates():
     y = model(xs[0])
     y.sum().backward()
     assert convs[0].weight.grad is not None
+
+
+def test_eval_caches_follow_weight_loading(tmp_path):
+    """Inference keeps BN constants and the first layer's padded filter pack between calls; load_weights (which writes
+    through .data, as the reference's cfg.py does) and in-place tensor updates must refresh them."""
+    from oracle.darknet_ref import seeded_state
+    model, _ = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 40)
+    other, _ = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 41)
+    wfile = str(tmp_path / 'other.weights')
+    other.save_weights(wfile)
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(0)).cuda()
+    model.eval(); other.eval()
+    with torch.no_grad():
+        y_a = model(x).clone()
+        y_b = other(x).clone()
+        assert not torch.equal(y_a, y_b)
+        model.load_weights(wfile)
+        assert torch.equal(model(x), y_b)
+        bn = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+        bn.running_var.mul_(2.0)                # in-place on the buffer itself: version counter bumps
+        bn_o = [m for m in other.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+        bn_o.running_var.mul_(2.0)
+        assert torch.equal(model(x), other(x))
+        assert not torch.equal(model(x), y_b)
