@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) 
 
   // ---- epilogue (conv_igemm_common.h) ----
   if constexpr ((ABL & 32) == 0) {
-    igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid);
+    igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid, p.ksplit > 1);
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -290,10 +290,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
                                                             const float* __restrict__ bias, float* stats, int M,
                                                             int Cout, int tile_m, int accumulate,
-                                                            const float* __restrict__ escale, float act_slope) {
+                                                            const float* __restrict__ escale, float act_slope,
+                                                            int row0) {
+  // rows [row0, M) (row0 a multiple of tile_m); workspace row m sits at m - row0, split stride (M - row0) rows
   const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
   const int c = blockIdx.y * 64 + gl * 4;
-  const int m0 = blockIdx.x * tile_m, m1 = min(M, m0 + tile_m);
+  const int m0 = row0 + blockIdx.x * tile_m, m1 = min(M, m0 + tile_m);
+  const int64_t ws_rows = M - row0;
+  ws -= (int64_t)row0 * Cout;
   const bool cok = c < Cout;           // Cout % 4 == 0 on this path (checked by the launcher)
   float cnt = 0.f;
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
@@ -305,7 +309,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     for (int m = m0 + pp; m < m1; m += 16) {
       f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
       for (int sp = 1; sp < ksplit; ++sp) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * M + m) * Cout + c);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * ws_rows + m) * Cout + c);
         v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
       }
       cnt += 1.f;
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     if (ch < Cout) {
       float n_ = red[0][q][0], mu = red[0][q][1 + k], s2 = red[0][q][5 + k];
       for (int w = 1; w < 16; ++w) chan_combine(n_, mu, s2, red[w][q][0], red[w][q][1 + k], red[w][q][5 + k]);
-      float* st = stats + ((int64_t)blockIdx.x * Cout + ch) * 2;
+      float* st = stats + ((int64_t)(m0 / tile_m) * Cout + ch) * 2;
       st[0] = mu;
       st[1] = s2;
     }
@@ -369,7 +373,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   return SSP_OK;
 }
 
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad, hipStream_t stream);   // conv_igemm_dma.hip
+int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int is_dgrad, hipStream_t stream);   // conv_igemm_dma.hip
 
 // Tile / split selection, a pure function of the layer shape (shared by the launcher and by the host-side queries
 // that size the BN-statistics and split-K workspaces).  128x128 tiles are the workhorse.  A grid that is not a whole
@@ -377,22 +381,25 @@ int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad
 // in its last wave: the 13x13 layers (680 tiles) would run 2 waves at 66 %.  Those layers split the K loop
 // (ksplit workgroups per tile, partial tiles summed by splitk_reduce_kernel) so the grid becomes ~4 full waves;
 // mid-size grids use 64-row tiles instead.
-struct IgemmPlan { int bm, ksplit, slots; };   // slots: LDS ring depth of the LDS-direct kernel (0 = its default)
+struct IgemmPlan { int bm, ksplit, slots, tail; };   // slots: LDS ring depth of the LDS-direct kernel (0 = its default);
+                                                      // tail: K split of the last partial wave's tiles (hybrid launch), 0 = off
 static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
-  IgemmPlan pl = {256, 1, 0};
+  IgemmPlan pl = {256, 1, 0, 0};
   if (Cout <= 64) {
     if (Cout > 32 && Cin % 16 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50) pl.bm = 128;   // 128x64 LDS-direct tiles
     return pl;
   }
   pl.bm = 128;
-  // explicit plan (engine autotuner: "igemm_plan" = bm*100 + ksplit*10 + slots); invalid requests fall back to auto
+  // explicit plan (engine autotuner: "igemm_plan" = tail*100000 + bm*100 + ksplit*10 + slots); invalid requests fall
+  // back to auto
   const int forced = ssp_option(SSP_OPT_IGEMM_PLAN);
   if (forced > 0) {
-    const int fbm = forced / 100, fks = (forced / 10) % 10, fsl = forced % 10;
+    const int ftail = forced / 100000, fbm = (forced / 100) % 1000, fks = (forced / 10) % 10, fsl = forced % 10;
     const int niter16 = (Cin % 16 == 0) ? R * R * (Cin / 16) : 0;
     const bool ok = (fbm == 64 || fbm == 128) && fks >= 1 && (fsl == 3 || fsl == 4) &&
-                    (fks == 1 || (niter16 / fks >= 8 && Cout % 4 == 0)) && Cin % 16 == 0;
-    if (ok) { pl.bm = fbm; pl.ksplit = fks; pl.slots = fsl; return pl; }
+                    (fks == 1 || (niter16 / fks >= 8 && Cout % 4 == 0)) && Cin % 16 == 0 &&
+                    (ftail == 0 || (ftail >= 2 && ftail <= 9 && fks == 1 && Cout % 4 == 0 && niter16 / ftail >= 8));
+    if (ok) { pl.bm = fbm; pl.ksplit = fks; pl.slots = fsl; pl.tail = ftail; return pl; }
   }
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);
   if (variant == 20 || variant == 22) { pl.bm = 64; return pl; }
@@ -423,7 +430,8 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
 int ssp_conv_tile_m(int M, int Cin, int Cout, int R) { return select_plan(M, Cin, Cout, R).bm; }
 int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R) {
   IgemmPlan pl = select_plan(M, Cin, Cout, R);
-  return pl.ksplit > 1 ? (int64_t)pl.ksplit * M * Cout : 0;
+  const int deepest = pl.ksplit > pl.tail ? pl.ksplit : pl.tail;      // a hybrid launch parks at most M rows x tail
+  return deepest > 1 ? (int64_t)deepest * M * Cout : 0;
 }
 
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
@@ -441,6 +449,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   a.probe = 0;
+  a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M;
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
   a.ksplit = pl.ksplit;
   a.ws = ws;
@@ -450,6 +459,11 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     SSP_CHECK_ARG(ws != nullptr && ws_floats >= (int64_t)pl.ksplit * a.M * Cout,
                   "conv: this shape runs split-K x%d and needs a workspace of %lld floats (ssp_conv_workspace_floats)",
                   pl.ksplit, (long long)pl.ksplit * a.M * Cout);
+  if (pl.tail > 1) {
+    SSP_CHECK_ARG(ws != nullptr && ws_floats >= (int64_t)pl.tail * a.M * Cout && ldout % 4 == 0 && (((uintptr_t)out) & 15) == 0,
+                  "conv: the hybrid plan (tail split x%d) needs an aligned output and a workspace of %lld floats "
+                  "(ssp_conv_workspace_floats)", pl.tail, (long long)pl.tail * a.M * Cout);
+  }
   SspProfScope prof(prof_kind, stream, 2.0 * (double)a.M * Cout * (double)(R * R * Cin));
   const int variant = ssp_option(SSP_OPT_IGEMM_VARIANT);   // experiments: tools/conv_bench.py --opt igemm_variant=N
   const int bk = (Cin % 32 == 0 && (variant == 2 || variant == 4 || variant == 5)) ? 32 : ((Cin % 16 == 0) ? 16 : 4);
@@ -472,7 +486,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       default: break;
     }
     if (bk >= 16 && variant != 50 && ((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
-      rc = ssp_conv_igemm_dma_launch(a, pl.bm, pl.slots, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
+      rc = ssp_conv_igemm_dma_launch(a, pl.bm, pl.slots, pl.tail, prof_kind == SSP_PROF_CONV_DGRAD, stream);      // LDS-direct loader (conv_igemm_dma.hip)
     } else if (pl.bm == 64) {
       rc = (bk >= 16) ? launch_cfg<64, 128, 2, 2, 16>(a, stream)
                       : (prof_kind == SSP_PROF_CONV_DGRAD ? launch_cfg<64, 128, 2, 2, 4, 0, 1>(a, stream) : launch_cfg<64, 128, 2, 2, 4>(a, stream));
@@ -487,19 +501,23 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     if (pl.bm == 128) {
       SSP_CHECK_ARG((int64_t)(128 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31),
                     "conv: image rows too long for the 32-bit tile offsets of the LDS-direct loader");
-      rc = ssp_conv_igemm_dma_launch(a, 128, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);
+      rc = ssp_conv_igemm_dma_launch(a, 128, 0, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);
     } else
       rc = (bk >= 16) ? launch_cfg<256, 64, 4, 1, 16>(a, stream) : launch_cfg<256, 64, 4, 1, 4>(a, stream);
   } else if (bk >= 16 && variant != 50 && ((int64_t)(256 + 2 * W + 2) * ldin * 4 + (int64_t)Cin * 4 < (1ll << 31))) {
-    rc = ssp_conv_igemm_dma_launch(a, 256, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);   // 256x32 LDS-direct tiles
+    rc = ssp_conv_igemm_dma_launch(a, 256, 0, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream);   // 256x32 LDS-direct tiles
   } else {
     rc = (bk >= 16) ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }
   if (rc != SSP_OK) return rc;
   if (pl.ksplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
-                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope);
+                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, 0);
     SSP_CHECK_LAUNCH("splitk_reduce");
+  } else if (a.tail_ks > 1) {     // hybrid launch: only the tail rows were left as partials
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
+                       a.tail_ks, out, ldout, bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, a.ws_row0);
+    SSP_CHECK_LAUNCH("splitk_reduce(tail)");
   }
   return SSP_OK;
 }

@@ -16,8 +16,13 @@ struct ConvArgs {
   int accumulate;     // out += result (second consumer of a routed activation in dgrad)
   int ntile_m, ntile_n;
   int xcd_remap;
-  float* ws;           // split-K partial tiles [ksplit][M][Cout] (ksplit > 1)
+  float* ws;           // split-K partial tiles [split][ws_rows][Cout], row m stored at m - ws_row0
   int ksplit, it_per_split;
+  // hybrid launch (LDS-direct kernel): tiles [0, tail_begin) run un-split and finish in their epilogue - whole resident
+  // waves of workgroups - and the remaining tiles, which would leave the last wave mostly idle, split their K loop
+  // tail_ks ways (partials to the workspace, summed by splitk_reduce_kernel over rows >= ws_row0).  tail_ks = 0: off.
+  int tail_begin, tail_ks, tail_it_per_split;
+  int ws_row0, ws_rows;
   int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
 };
 
@@ -37,14 +42,14 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `smem` must be free (all LDS traffic of the K loop retired).
 template <int BM, int BN, int WM, int WN, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                               int m0, int n0, int tile_m, int split, int tid) {
+                                               int m0, int n0, int tile_m, int split, int tid, bool partial) {
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int li = lane & 31, lh = lane >> 5;
-  if (p.ksplit > 1) {
+  if (partial) {
     // split-K: raw partial tile to the workspace; bias / accumulate / BN statistics happen in splitk_reduce_kernel
-    float* wsp = p.ws + (int64_t)split * p.M * p.Cout;
+    float* wsp = p.ws + ((int64_t)split * p.ws_rows - p.ws_row0) * p.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WTN + j * 32 + li;

@@ -48,9 +48,31 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   char* const lds = reinterpret_cast<char*>(smem);
 
   const int ntiles = p.ntile_m * p.ntile_n;
-  const int nwg = ntiles * p.ksplit;
-  const int lid0 = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
-  const int split = lid0 / ntiles, lid = lid0 - split * ntiles;
+  int split, lid;
+  bool partial;
+  if (p.tail_ks > 0) {
+    // hybrid: workgroups [0, tail_begin) = whole un-split tiles; the rest = the tail tiles x tail_ks K ranges.  The XCD
+    // remap permutes each group on its own so that the short tail workgroups are dispatched last, on every XCD.
+    const int ntail = ntiles - p.tail_begin;
+    if ((int)blockIdx.x < p.tail_begin) {
+      lid = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, p.tail_begin) : (int)blockIdx.x;
+      split = 0;
+      partial = false;
+    } else {
+      const int nt = ntail * p.tail_ks;
+      const int t0 = (int)blockIdx.x - p.tail_begin;
+      const int t = p.xcd_remap ? ssp_xcd_remap(t0, nt) : t0;
+      split = t / ntail;
+      lid = p.tail_begin + (t - split * ntail);
+      partial = true;
+    }
+  } else {
+    const int nwg = ntiles * p.ksplit;
+    const int lid0 = p.xcd_remap ? ssp_xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+    split = lid0 / ntiles;
+    lid = lid0 - split * ntiles;
+    partial = p.ksplit > 1;
+  }
   const int tile_n = lid % p.ntile_n, tile_m = lid / p.ntile_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -62,8 +84,9 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   const int K = p.R * p.R * p.Cin;
   const int cpt = p.Cin / BK;
   const int niter_all = p.R * p.R * cpt;
-  const int it_begin = split * p.it_per_split;
-  const int niter = min(niter_all, it_begin + p.it_per_split) - it_begin;
+  const int it_ps = (p.tail_ks > 0) ? (partial ? p.tail_it_per_split : niter_all) : p.it_per_split;
+  const int it_begin = split * it_ps;
+  const int niter = min(niter_all, it_begin + it_ps) - it_begin;
 
   // ---- buffer descriptors: A starts (W+1) pixels before the tile so every tap offset is non-negative ----
   const int halo = p.W + 1;
@@ -227,50 +250,76 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   __builtin_amdgcn_s_barrier();
 
   if (p.probe == 1 && acc[0][0][0] != 12345.678f) return;
-  igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid);
+  igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid, partial);
 #endif
 }
 
 template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
-static int launch_dma(ConvArgs a, hipStream_t stream) {
+static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
   const int niter_total = a.R * a.R * (a.Cin / 16);
   a.probe = ssp_option(SSP_OPT_IGEMM_VARIANT) == 60 ? 1 : 0;
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
-  dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(256);
   const int lds_bytes = NSLOT * (BM + BN) * 64 + ((BN % 64) ? 1024 : 0);
   auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT, WM, WN>;
   static int configured = 0;
+  static int slots = 0;       // workgroups resident on the whole chip at once
   if (lds_bytes > configured) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
       ssp_set_error("conv_igemm_dma: cannot reserve %d bytes of LDS", lds_bytes);
       return SSP_ERR_HIP;
     }
     configured = lds_bytes;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 2;
+    slots = per_cu * 256;
   }
-  hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+  // hybrid launch: as many whole resident waves of un-split tiles as fit, the rest of the tiles split tail_ks ways
+  a.tail_ks = 0;
+  a.tail_begin = a.ntile_m * a.ntile_n;
+  a.ws_row0 = 0;
+  a.ws_rows = a.M;
+  unsigned nwg = (unsigned)(a.ntile_m * a.ntile_n * a.ksplit);
+  if (tail_ks > 1 && a.ksplit == 1 && a.ws != nullptr && a.Cout % 4 == 0 && niter_total / tail_ks >= 8) {
+    const int64_t tiles = (int64_t)a.ntile_m * a.ntile_n;
+    const int64_t full = tiles / slots;                              // whole waves
+    const int tm1 = (int)((full * slots) / a.ntile_n);               // first tile row of the tail
+    if (full >= 1 && tm1 < a.ntile_m) {
+      a.tail_ks = tail_ks;
+      a.tail_it_per_split = ssp_cdiv(niter_total, tail_ks);
+      a.tail_ks = ssp_cdiv(niter_total, a.tail_it_per_split);
+      a.tail_begin = tm1 * a.ntile_n;
+      a.ws_row0 = tm1 * BM;
+      a.ws_rows = a.M - a.ws_row0;
+      nwg = (unsigned)(a.tail_begin + (a.ntile_m - tm1) * a.ntile_n * a.tail_ks);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_igemm_dma");
   return SSP_OK;
 }
 
 // bm in {64, 128} with BN = 128, 128 x 64 tiles for Cout <= 64, 256 x 32 tiles for Cout <= 32.  Preconditions (checked by the caller): Cin % 16 == 0, 16-byte aligned operands,
 // ldin % 4 == 0, and every byte offset of a tile (rows + halo) below 2^31.
-int ssp_conv_igemm_dma_launch(const ConvArgs& a, int bm, int slots, int is_dgrad, hipStream_t stream) {
+int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int is_dgrad, hipStream_t stream) {
   // ring depth: 3 slots (48 KB, 3 workgroups per CU) for un-split 128x128 grids and the 128x64 tiles - the third wave
   // per SIMD covers the barrier / LDS-latency bubbles better than the deeper prefetch does (measured +4..6 % on layers
   // 2-8); split-K launches and 64x128 tiles keep 4 slots.  `slots` (3 / 4) from an explicit plan overrides this.
+  // On return a.tail_ks > 0 tells the caller that rows >= a.ws_row0 were left as partials in the workspace.
   bool three = (bm == 128 && a.Cout > 64 && a.ksplit == 1) || a.Cout <= 64;
   if (slots == 3) three = true;
   if (slots == 4) three = false;
-  if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, stream);
+  const int tk = tail_ks;
+  if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, 0, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, 0, stream);
   if (is_dgrad) {
-    if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, stream) : launch_dma<128, 64, 1>(a, stream);
-    if (bm == 64) return three ? launch_dma<64, 128, 1, 3>(a, stream) : launch_dma<64, 128, 1>(a, stream);
-    return three ? launch_dma<128, 128, 1, 3>(a, stream) : launch_dma<128, 128, 1>(a, stream);
+    if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, tk, stream) : launch_dma<128, 64, 1>(a, tk, stream);
+    if (bm == 64) return three ? launch_dma<64, 128, 1, 3>(a, tk, stream) : launch_dma<64, 128, 1>(a, tk, stream);
+    return three ? launch_dma<128, 128, 1, 3>(a, tk, stream) : launch_dma<128, 128, 1>(a, tk, stream);
   }
-  if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3>(a, stream) : launch_dma<128, 64, 0>(a, stream);
-  if (bm == 64) return three ? launch_dma<64, 128, 0, 3>(a, stream) : launch_dma<64, 128, 0>(a, stream);
-  return three ? launch_dma<128, 128, 0, 3>(a, stream) : launch_dma<128, 128, 0>(a, stream);
+  if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3>(a, tk, stream) : launch_dma<128, 64, 0>(a, tk, stream);
+  if (bm == 64) return three ? launch_dma<64, 128, 0, 3>(a, tk, stream) : launch_dma<64, 128, 0>(a, tk, stream);
+  return three ? launch_dma<128, 128, 0, 3>(a, tk, stream) : launch_dma<128, 128, 0>(a, tk, stream);
 }

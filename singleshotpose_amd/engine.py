@@ -334,7 +334,9 @@ class Plan(object):
         f32 = dict(dtype=torch.float32, device=self.device)
         _tune_cache_load()
         n_known = len(_TUNE_CACHE)
-        cands = (12813, 12814, 6414, 6413, 12824, 12834)
+        # tile rows x split-K x ring depth; 3xxxxx / 2xxxxx = hybrid launches (whole resident waves un-split, the tiles of
+        # the last partial wave split 3 / 2 ways over K)
+        cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814)
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
             return
@@ -354,8 +356,8 @@ class Plan(object):
             # deep K splits put every CU on the weight stream
             deep = (12864, 12894, 6464, 6494) if mn <= (1 << 21) else ()
             for code in cands + deep:
-                if (code // 10) % 10 > 1 and mn > (1 << 25):
-                    continue
+                if ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
+                    continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
                 call('ssp_set_option', b'igemm_plan', code)
                 try:
                     launch()

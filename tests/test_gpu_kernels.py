@@ -350,3 +350,50 @@ def test_conv_fwd_affine_eval_block(B, H, W, Cin, Cout, R, plan, slope, with_sca
     finally:
         _lib.call('ssp_set_option', b'igemm_plan', 0)
     assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("plan", [306413, 212814, 306414])
+def test_conv_hybrid_launch_matches_plain(plan):
+    """Hybrid launch (whole resident waves of un-split tiles + the tail tiles split over K, one launch + a partial-sum
+    pass over the tail rows): output, accumulate mode and BatchNorm statistics against the plain launch of the same
+    tiling.  16 x 52 x 52 pixels, 128 -> 256 channels: 1352 (64-row) / 676 (128-row) tiles, more than one resident wave."""
+    G, _lib = _imports()
+    B, H, W, Cin, Cout, R = 16, 52, 52, 128, 256, 3
+    rs = np.random.RandomState(plan % 1000)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, R, R)) / np.sqrt(Cin * R * R)).astype(np.float32))
+    xd, wd = G.to_nhwc(x), G.pack_fwd(w, Cin)
+    M = B * H * W
+
+    def run(code, accumulate_twice=False):
+        _lib.call('ssp_set_option', b'igemm_plan', code)
+        try:
+            tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, R)
+            wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R))
+            ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+            ntile = (M + tile_m - 1) // tile_m
+            stats = torch.full((ntile * Cout * 2,), float('nan'), dtype=torch.float32, device=G.dev())
+            out = torch.zeros(M, Cout, dtype=torch.float32, device=G.dev())
+            _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, stats.data_ptr(), B, H, W, Cin,
+                      Cout, Cin, Cout, R, 0, ws.data_ptr(), wsn, G.stream())
+            if accumulate_twice:
+                _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout,
+                          Cin, Cout, R, 1, ws.data_ptr(), wsn, G.stream())
+            torch.cuda.synchronize()
+            return out.cpu().numpy(), stats.cpu().numpy().reshape(ntile, Cout, 2), tile_m, wsn
+        finally:
+            _lib.call('ssp_set_option', b'igemm_plan', 0)
+    base = plan % 100000
+    o_plain, s_plain, tm_plain, ws_plain = run(base)
+    o_hyb, s_hyb, tm_hyb, ws_hyb = run(plan)
+    assert tm_plain == tm_hyb and ws_hyb >= (plan // 100000) * M * Cout > ws_plain
+    assert rel_err(o_hyb, o_plain) < 1e-5
+    assert not np.isnan(s_hyb).any()
+    np.testing.assert_allclose(s_hyb[:, :, 0], s_plain[:, :, 0], rtol=1e-4, atol=1e-5)      # per-tile means
+    np.testing.assert_allclose(s_hyb[:, :, 1], s_plain[:, :, 1], rtol=1e-3)                 # per-tile M2
+    o2, _, _, _ = run(plan, accumulate_twice=True)
+    assert rel_err(o2, 2 * o_plain) < 1e-5
+    # the plain-PyTorch check of the same convolution on a slice of the batch (covers main and tail rows: last images)
+    ref = F.conv2d(x[-2:], w, None, padding=1)
+    got = G.from_nhwc(torch.from_numpy(o_hyb[-2 * H * W:]), 2, Cout, H, W)
+    assert rel_err(got.numpy(), ref.numpy()) < TOL
