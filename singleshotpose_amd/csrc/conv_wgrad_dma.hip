@@ -21,6 +21,7 @@ struct WgradArgs {
   float* dw;
   int H, W, Cin, Cout, lddy, ldx, R, M;
   int ntile_co, ntile_ci, nsplit, chunk_m;
+  int xcd_order;  // XCD-aware workgroup order (see the kernel)
   int no_store;   // timing probe (wgrad_variant 9): skip the atomic epilogue - results are wrong on purpose
   int fold;   // filter taps per cin tile: 1, or BNI / Cin when Cin < BNI (thin layers: two taps of 32 cins share a tile)
 };
@@ -72,8 +73,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 
   const int taps = p.R * p.R;
   const int tap_groups = (taps + p.fold - 1) / p.fold;
-  int bid = blockIdx.x;
-  const int split = bid % p.nsplit; bid /= p.nsplit;
+  // Workgroup order.  All taps x tiles of one pixel range read the same dY / X rows; dispatch hands consecutive
+  // workgroup ids to the 8 XCDs round robin and each XCD has its own L2.  xcd_order: the workgroups of pixel range s sit
+  // on XCD s % 8, consecutively in its dispatch order, so they stream those rows through that L2 together (the plain
+  // order spreads each range over all XCDs and over time: every tap re-fetches the operands from HBM).
+  int split, bid;
+  if (p.xcd_order) {
+    const int G = tap_groups * p.ntile_ci * p.ntile_co;
+    const int x = blockIdx.x % 8, q = blockIdx.x / 8;
+    split = x + 8 * (q / G);
+    bid = q % G;
+    if (split >= p.nsplit) return;      // grid padded to a multiple of 8 pixel ranges
+  } else {
+    bid = blockIdx.x;
+    split = bid % p.nsplit; bid /= p.nsplit;
+  }
   const int tap = (bid % tap_groups) * p.fold; bid /= tap_groups;   // first tap of this workgroup's tile
   const int tile_ci = bid % p.ntile_ci;
   const int tile_co = bid / p.ntile_ci;
@@ -344,9 +358,19 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   if (hi < lo) hi = lo;
   if (lo > max_split) lo = max_split;
   if (hi > max_split) hi = max_split;
+  // XCD-aware order (see the kernel) when the workgroups of one pixel range fit one XCD's resident set (64); the split
+  // is then a multiple of 8 so that every XCD gets the same number of pixel ranges
+  a.xcd_order = (variant != 10 && tiles <= 64 && max_split >= 16) ? 1 : 0;
+  const int64_t step = a.xcd_order ? 8 : 1;
+  if (a.xcd_order) {
+    lo = (lo + 7) / 8 * 8;
+    hi = hi / 8 * 8;
+    if (hi < lo) hi = lo;
+    if (lo > max_split) { a.xcd_order = 0; lo = max_split; hi = max_split; }
+  }
   int64_t nsplit = lo;
   double best = -1.0;
-  for (int64_t sp = lo; sp <= hi; ++sp) {
+  for (int64_t sp = lo; sp <= hi; sp += (a.xcd_order ? step : 1)) {
     const double waves = (double)(tiles * sp) / slots;
     const double eff = waves / (double)((tiles * sp + slots - 1) / slots);
     if (eff > best + 1e-3) { best = eff; nsplit = sp; }
@@ -357,7 +381,8 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   nsplit = (a.M + chunk - 1) / chunk;
   a.nsplit = (int)nsplit;
   a.chunk_m = (int)chunk;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * nsplit)), dim3(256), lds_bytes, stream, a);
+  const int64_t nwg = a.xcd_order ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_wgrad_dma");
   return SSP_OK;
 }
