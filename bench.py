@@ -105,6 +105,9 @@ def main():
     ap.add_argument('--cfg', default=os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--timers', default='conv', choices=['conv', 'all', 'none'],
+                    help='launches bracketed by HIP events INSIDE the timed region: conv = forward conv launches only '
+                         '(what the roofline needs), all = every launch, none')
     ap.add_argument('--opt', default='', help='kernel experiment knobs, name=value,... (ssp_set_option); default: none')
     args = ap.parse_args()
 
@@ -157,20 +160,37 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    _lib.call('ssp_prof_enable', 1)
+    import ctypes
+    nk = _lib.query('ssp_prof_nkinds')
+
+    def collect():
+        ms = (ctypes.c_double * nk)()
+        work = (ctypes.c_double * nk)()
+        cnt = (ctypes.c_int64 * nk)()
+        _lib.call('ssp_prof_collect', ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p),
+                  ctypes.cast(cnt, ctypes.c_void_p))
+        return list(ms), list(work), list(cnt)
+
+    # Timed region: HIP events only around the FORWARD launches of the dominant kernel (what `roofline` needs; every
+    # timed launch adds two event packets to its stream: all ~240 launches of a step timed cost 0.9 ms, these 23 cost
+    # <0.1 ms).  --timers all / none change that.
+    _lib.call('ssp_prof_enable', {'conv': 0b001, 'all': -1, 'none': 0}[args.timers])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
     _lib.call('ssp_prof_enable', 0)
-    nk = _lib.query('ssp_prof_nkinds')
-    import ctypes
-    ms = (ctypes.c_double * nk)()
-    work = (ctypes.c_double * nk)()
-    cnt = (ctypes.c_int64 * nk)()
-    _lib.call('ssp_prof_collect', ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p),
-              ctypes.cast(cnt, ctypes.c_void_p))
+    ms, work, cnt = collect()
+    # Per-family breakdown (kernel_ms_per_step, roofline_bwd): a separate, untimed pass of the same steps with every
+    # launch bracketed by events.
+    nb = min(args.steps, 5)
+    _lib.call('ssp_prof_enable', -1)
+    for _ in range(nb):
+        loss = step()
+    barrier()
+    _lib.call('ssp_prof_enable', 0)
+    bms, bwork, bcnt = collect()
     final_loss = float(loss)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -180,15 +200,17 @@ def main():
 
     if rank == 0:
         kinds = _lib.PROF_KINDS
-        prof = {kinds[k]: {"ms_per_step": ms[k] / args.steps, "launches_per_step": cnt[k] / args.steps,
-                           "work_per_step": work[k] / args.steps} for k in range(nk)}
+        prof = {kinds[k]: {"ms_per_step": bms[k] / nb, "launches_per_step": bcnt[k] / nb,
+                           "work_per_step": bwork[k] / nb} for k in range(nk)}
         # Dominant kernel = the implicit-GEMM conv kernel.  Its FORWARD launches run alone on the GPU, so their HIP-event
         # durations are kernel-exclusive; the same kernel's data-gradient launches overlap the filter-gradient kernel
         # on a second stream (Plan.backward), which stretches both their event durations - they are reported apart.
-        ig_ms, ig_flop, ig_n = ms[0], work[0], cnt[0]
+        ig_ms, ig_flop, ig_n, ig_steps = ms[0], work[0], cnt[0], args.steps
+        if ig_ms <= 0:      # --timers none: take the forward launches of the breakdown pass
+            ig_ms, ig_flop, ig_n, ig_steps = bms[0], bwork[0], bcnt[0], nb
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        bwd_ms = max(ms[1], ms[2])   # the two streams run concurrently: wall time of the conv backward ~ the longer one
-        bwd_tf = (work[1] + work[2]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        bwd_ms = max(bms[1], bms[2])   # the two streams run concurrently: wall time of the conv backward ~ the longer one
+        bwd_tf = (bwork[1] + bwork[2]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         traffic, traffic_src = forward_traffic_per_launch()
         images_per_s = global_batch * args.steps / dt
         res = {
@@ -212,12 +234,13 @@ def main():
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
-                         "launches_per_step": ig_n / args.steps,
+                         "launches_per_step": ig_n / ig_steps,
                          "flop_per_launch_avg": ig_flop / max(ig_n, 1)},
             "roofline_bwd": {"bound": "mfma", "kernel": "conv dgrad (stream 1) overlapped with conv_wgrad_kernel (stream 2)",
                              "achieved": round(bwd_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(bwd_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                             "note": "algorithmic dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times)"},
+                             "note": "algorithmic dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times); "
+                                     "from a separate untimed pass with every launch timed, as kernel_ms_per_step"},
             "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()},
             "final_loss": final_loss,

@@ -143,7 +143,9 @@ int ssp_pose_errors(const double* vertices, int N, const double* Rt_gt, const do
 int ssp_pts_diameter(const double* pts, int N, double* out, double* scratch, void* stream);
 
 /* ---- timed-launch bookkeeping (bench.py roofline): HIP events around every launch of a kernel family -------- */
-int ssp_prof_enable(int on);
+/* mask: bit k = kernel family k (0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 BN/activation, 4 layout, 5 region/pnp/eval,
+ * 6 optimizer); -1 = all, 0 = off.  Every timed launch costs two event packets on its stream. */
+int ssp_prof_enable(int mask);
 /* ms[k], work[k] (FLOPs or bytes), count[k] for k in 0..ssp_prof_nkinds()-1; synchronises on the recorded events */
 int ssp_prof_nkinds(void);
 int ssp_prof_collect(double* ms, double* work, int64_t* count);

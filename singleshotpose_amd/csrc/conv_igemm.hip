@@ -449,7 +449,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   a.probe = 0;
-  a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M;
+  a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
   a.ksplit = pl.ksplit;
   a.ws = ws;

@@ -23,6 +23,7 @@ struct ConvArgs {
   // tail_ks ways (partials to the workspace, summed by splitk_reduce_kernel over rows >= ws_row0).  tail_ks = 0: off.
   int tail_begin, tail_ks, tail_it_per_split;
   int ws_row0, ws_rows;
+  int col_major;       // tile order inside a launch: tile_m fastest (workgroups resident on one XCD share a filter slab)
   int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
 };
 

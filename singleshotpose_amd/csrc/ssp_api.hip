@@ -82,13 +82,13 @@ struct ProfRec {
   double work;
 };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;   // bit k: launches of family k are bracketed by HIP events
 std::vector<ProfRec> g_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
 }  // namespace
 
 SspProfScope::SspProfScope(int kind, hipStream_t s, double work) : slot(-1), stream(s) {
-  if (!g_prof_on) return;
+  if (!((g_prof_mask >> kind) & 1u)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.kind = kind;
@@ -249,7 +249,7 @@ int ssp_pnp_batched(const double* pts3d, const double* pts2d, const double* K, d
 
 int ssp_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_on = on != 0;
+  g_prof_mask = (unsigned)on;     // bit k = family k (SSP_PROF_*); -1 = every family, 0 = off
   return SSP_OK;
 }
 int ssp_pose_errors(const double* vertices, int N, const double* Rt_gt, const double* Rt_pr, const double* K,
