@@ -407,7 +407,7 @@ class Plan(object):
         else:
             call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
         # Filter repacks depend only on the weights, not on the activations: they run on the side stream, ahead of the
-        # convolutions that use them, instead of as one more dependent launch (~4 us of work + ~12 us of launch gap)
+        # convolutions that use them, instead of as one more dependent launch
         # in front of every conv on the main stream.  Forward operands first (two events: the first four layers, then
         # the rest), then - when a backward will follow - the flipped/transposed data-gradient operands, which hide
         # under the MFMA-bound forward convs instead of sitting on the critical path of backward.
