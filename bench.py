@@ -9,8 +9,9 @@ synthetic 416x416 batches, 64 images per GPU (BASELINE.json metric).
 Prints ONE JSON line on rank 0.  `value` = images/s of the whole job (all ranks), max-over-ranks time of exactly K
 steps between barrier + synchronize pairs, inputs resident in HBM.  `roofline` is for the dominant kernel
 (the implicit-GEMM conv kernel): algorithmic conv FLOPs of its forward launches / their HIP-event time, against the
-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); the backward conv launches overlap on two streams and are
-reported together in `roofline_bwd`.  `cpu_baseline` times the CPU oracle of the same step
+fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), from HIP events around exactly those launches inside the timed
+region; the backward conv launches overlap on two streams and are reported together in `roofline_bwd`, which - like
+`kernel_ms_per_step` - comes from a second, untimed pass with every launch bracketed by events.  `cpu_baseline` times the CPU oracle of the same step
 (oracle/: the reference's PyTorch-CPU semantics) on this host for a bounded batch - rank 0, N=1 only.
 """
 import argparse
