@@ -200,3 +200,41 @@ def test_fused_sgd_constructor_mirrors_torch():
                 dict(lr=0.1, nesterov=True), dict(lr=0.1, momentum=0.9, dampening=0.1, nesterov=True)):
         with pytest.raises(ValueError):
             SGD([p], **bad)
+
+
+def test_dropin_modules_resolve_like_the_reference_scripts(tmp_path):
+    """`PYTHONPATH=repo:repo/dropin` makes the reference's own import lines (train.py:18-23, valid.py:8-13,
+    train_multi.py / valid_multi.py) resolve to this package: run them in a fresh interpreter."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import cv2                                   # train.py:15 / valid.py:8: the stand-in (never called on the hot path)
+from darknet import Darknet                  # train.py:18
+from cfg import parse_cfg                    # train.py:19
+from region_loss import RegionLoss           # train.py:21
+from utils import *                          # train.py:22
+import utils
+for n in """makedirs get_all_files calcAngularDistance get_camera_intrinsic compute_projection compute_transformation
+calc_pts_diameter adi get_3D_corners pnp get_2d_bb compute_2d_bb compute_2d_bb_from_orig_pix corner_confidences
+corner_confidence sigmoid softmax fix_corner_order convert2cpu convert2cpu_long get_region_boxes read_truths
+read_truths_args read_pose load_class_names image2torch read_data_cfg scale_bboxes file_lines get_image_size
+logging""".split():
+    assert callable(getattr(utils, n)), n
+import singleshotpose_amd
+assert Darknet is singleshotpose_amd.darknet.Darknet and RegionLoss is singleshotpose_amd.region_loss.RegionLoss
+m = Darknet(r"%s")
+assert m.loss.__class__ is RegionLoss or m.loss.__class__.__name__ == "RegionLoss"
+assert len(parse_cfg(r"%s")) == 33
+import sys, os
+sys.path.insert(0, os.path.join(r"%s", "dropin", "multi_obj_pose_estimation"))
+from darknet_multi import Darknet as DM      # train_multi.py
+from region_loss_multi import RegionLoss as RLM
+import utils_multi
+for n in "bbox_iou nms get_multi_region_boxes corner_confidences pnp get_3D_corners".split():
+    assert callable(getattr(utils_multi, n)), n
+print("ok")
+''' % (os.path.join(root, 'cfg', 'yolo-pose.cfg'), os.path.join(root, 'cfg', 'yolo-pose.cfg'), root)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, 'dropin')]))
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
