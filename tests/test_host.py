@@ -238,3 +238,33 @@ print("ok")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, 'dropin')]))
     out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+def test_tune_cache_round_trip(tmp_path, monkeypatch):
+    """SSP_TUNE_CACHE=<file>: the autotuner's per-shape plan choices survive the process (host logic, no GPU)."""
+    from singleshotpose_amd import engine
+    path = str(tmp_path / 'tune.json')
+    monkeypatch.setenv('SSP_TUNE_CACHE', path)
+    saved = dict(engine._TUNE_CACHE)
+    old_file = engine._TUNE_CACHE_FILE[0]
+    try:
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE_FILE[0] = None
+        engine._tune_cache_load()                      # no file yet: nothing loaded, path remembered
+        key = ('fwd', 64, 13, 13, 512, 1024, 3, 512, 1024, True)
+        engine._TUNE_CACHE[key] = 306413
+        engine._TUNE_CACHE[('dgrad', 64, 26, 26, 512, 256, 3, 512, 256)] = 6413
+        engine._tune_cache_save()
+        assert os.path.isfile(path)
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE_FILE[0] = None
+        engine._tune_cache_load()
+        assert engine._TUNE_CACHE[key] == 306413 and len(engine._TUNE_CACHE) == 2
+        engine._TUNE_CACHE[key] = 12813                # an in-process choice is not overwritten by the file
+        engine._TUNE_CACHE_FILE[0] = None
+        engine._tune_cache_load()
+        assert engine._TUNE_CACHE[key] == 12813
+    finally:
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_CACHE.update(saved)
+        engine._TUNE_CACHE_FILE[0] = old_file
