@@ -159,6 +159,14 @@ def test_pnp_round_trip_and_oracle():
         R_o, t_o = solve_pnp_ref(X, uvn[i], K)
         assert np.abs(project(X, R_g[i], t_g[i], K) - project(X, R_o, t_o, K)).max() < 1e-3
         assert abs(np.linalg.det(R_g[i]) - 1) < 1e-9 and np.abs(R_g[i].dot(R_g[i].T) - np.eye(3)).max() < 1e-9
+    # independent pin (no OpenCV here): scipy's MINPACK LM on the same reprojection objective, started from the TRUE
+    # pose, reaches the same minimum as the kernel
+    from test_host import _scipy_pnp
+    for i in range(0, n, 8):
+        R_s, t_s, cost_s = _scipy_pnp(X, uvn[i], K, Rs[i], ts[i])
+        cost_g = float(((project(X, R_g[i], t_g[i], K) - uvn[i]) ** 2).sum())
+        assert abs(cost_g - cost_s) <= 1e-7 * max(cost_s, 1.0)
+        assert np.abs(project(X, R_g[i], t_g[i], K) - project(X, R_s, t_s, K)).max() < 1e-3
     # reference signature: float32 inputs, (3,3)/(3,1) float64 outputs
     R1, t1 = pnp(X.astype(np.float32), uvs[0].astype(np.float32), K.astype(np.float32))
     assert R1.shape == (3, 3) and t1.shape == (3, 1) and R1.dtype == np.float64

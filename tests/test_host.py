@@ -268,3 +268,40 @@ def test_tune_cache_round_trip(tmp_path, monkeypatch):
         engine._TUNE_CACHE.clear()
         engine._TUNE_CACHE.update(saved)
         engine._TUNE_CACHE_FILE[0] = old_file
+
+
+def _scipy_pnp(X, uv, K, R0, t0):
+    """Independent minimiser of the pixel reprojection error (the objective cv2.solvePnP's ITERATIVE flag minimises):
+    scipy's MINPACK Levenberg-Marquardt over (rotation vector, t), started from (R0, t0)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    x0 = np.concatenate([Rotation.from_matrix(R0).as_rotvec(), np.asarray(t0).ravel()])
+
+    def resid(p):
+        R = Rotation.from_rotvec(p[:3]).as_matrix()
+        cam = X.dot(R.T) + p[3:]
+        proj = cam[:, :2] / cam[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+        return (proj - uv).ravel()
+    sol = least_squares(resid, x0, method='lm', xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    return Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:], float((sol.fun ** 2).sum())
+
+
+def test_pnp_oracle_matches_independent_least_squares_solver():
+    """PnP parity is unpinned against OpenCV (not installable here).  What CAN be pinned: the ITERATIVE flag returns the
+    Levenberg-Marquardt minimiser of the pixel reprojection error; an independent solver (scipy / MINPACK) must land on
+    the same pose from noisy corners, whatever the starting point."""
+    from oracle.pnp_ref import project, rodrigues, solve_pnp_ref
+    K = np.array([[572.4114, 0, 325.2611], [0, 573.5704, 242.0489], [0, 0, 1.0]])
+    X = np.concatenate([np.zeros((1, 3)), np.array([[sx * .038, sy * .039, sz * .046] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])], 0)
+    rs = np.random.RandomState(5)
+    for _ in range(10):
+        axis = rs.standard_normal(3)
+        R = rodrigues(axis / np.linalg.norm(axis) * rs.uniform(0, np.pi / 3))
+        t = np.array([rs.uniform(-.1, .1), rs.uniform(-.1, .1), rs.uniform(.6, 1.2)])
+        uvn = project(X, R, t, K) + rs.uniform(-1, 1, (9, 2))
+        R1, t1 = solve_pnp_ref(X, uvn, K)
+        R2, t2, cost2 = _scipy_pnp(X, uvn, K, R, t)              # started from the TRUE pose, not from ours
+        cost1 = float(((project(X, R1, t1, K) - uvn) ** 2).sum())
+        assert abs(cost1 - cost2) <= 1e-7 * max(cost2, 1.0)
+        assert np.abs(project(X, R1, t1, K) - project(X, R2, t2, K)).max() < 1e-3
+        assert np.abs(R1 - R2).max() < 1e-4 and np.abs(np.asarray(t1).ravel() - t2).max() < 1e-4
