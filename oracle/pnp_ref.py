@@ -6,7 +6,8 @@ installable in this environment and the reference has no test or golden vector f
 restates OpenCV's published non-planar algorithm (calib3d: DLT initialisation, det>0 sign fix, SVD projection on
 SO(3), translation rescale, then Levenberg-Marquardt on the pixel reprojection error with CvLevMarq's schedule:
 lambda 1e-3, x10 on a worse step, /10 on a better one, <= 20 accepted steps, stop at |dp|/|p| < FLT_EPSILON) and is
-checked by synthetic round trips (project a known pose, recover it) instead of by reference outputs.
+checked by synthetic round trips (project a known pose, recover it) instead of by reference outputs, plus a
+cross-check against an independent minimiser of the same objective (scipy MINPACK LM, tests/test_host.py).
 """
 import numpy as np
 
