@@ -22,8 +22,9 @@ extern "C" {
 
 const char* ssp_last_error(void);
 int ssp_abi_version(void);
-/* tuning knobs (kernel variant / tile selection); unknown names are an error.  Never changes results beyond fp32
- * summation order. */
+/* EXPERIMENT knobs (kernel variant / tile-order A-B switches used by bench.py --opt and tools/): process-wide, not
+ * synchronised, never written by the product path (engine.Plan passes its per-launch choices as explicit `plan`
+ * arguments below).  Unknown names are an error.  Never changes results beyond fp32 summation order. */
 int ssp_set_option(const char* name, int value);
 
 /* ---- convolution (stride 1, "same" padding, R = 1 or 3): nn.Conv2d at darknet.py:156,160 ------------------- */
@@ -33,23 +34,29 @@ int ssp_set_option(const char* name, int value);
  * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157).
  * workspace: ssp_conv_workspace_floats(...) floats (0 for most shapes; the 13x13 layers split their K loop over
  * several workgroups per tile and sum the partial tiles from it).  The shape arguments of the two queries are those
- * of the launch (for ssp_conv_dgrad: Cin = channels of dy, Cout = channels of dx). */
+ * of the launch (for ssp_conv_dgrad: Cin = channels of dy, Cout = channels of dx).
+ * plan: tile / split choice of THIS launch, 0 = the library's shape heuristic, else
+ *   tail*100000 + tile_rows*100 + ksplit*10 + ring_slots   (tile_rows 64|128, ksplit 1..9, ring_slots 3|4,
+ *   tail 0 or 2..9 = hybrid launch: whole resident waves un-split, the last partial wave's tiles split `tail` ways);
+ * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
+ * models) may run different plans concurrently.  The same code must be passed to the two queries. */
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
-                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* workspace,
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int plan, float* workspace,
                  int64_t workspace_floats, void* stream);
 /* eval-mode block in one launch (darknet.py:154-167 with BatchNorm in inference mode):
  * out[p][co] = leaky(scale[co] * conv(in, wt)[p][co] + shift[co], slope); scale / shift from ssp_bn_eval_prepare
  * (either may be NULL = 1 / 0), slope = 1 for a linear block.  Same shapes, workspace and limits as ssp_conv_fwd. */
 int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const float* scale, const float* shift,
-                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R,
+                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R, int plan,
                         float* workspace, int64_t workspace_floats, void* stream);
-int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R);
-int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R);
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int plan);
+int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan);
 
 /* data gradient (autograd of nn.Conv2d, train.py:103): dx[p][ci] (+)= sum dy[p - tap][co] * w[co][ci][tap];
  * same contraction as ssp_conv_fwd with `wt` from ssp_repack_dgrad; Cout_dy = channels of dy (multiple of 4). */
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
-                   int lddx, int R, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
+                   int lddx, int R, int accumulate, int plan, float* workspace, int64_t workspace_floats,
+                   void* stream);
 
 /* filter gradient: dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]; dw is [Cout][R*R][Cin] packed and must be
  * zeroed by the caller (split reduction uses fp32 atomics). */

@@ -26,11 +26,11 @@ L = c_int64
 _SIGS = {
     "ssp_abi_version": [],
     "ssp_set_option": [c_char_p, I],
-    "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
-    "ssp_conv_fwd_affine": [P, P, P, P, P, F, I, I, I, I, I, I, I, I, P, L, P],
-    "ssp_conv_stats_tile_m": [I, I, I, I, I, I],
-    "ssp_conv_workspace_floats": [I, I, I, I, I, I],
-    "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_fwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_fwd_affine": [P, P, P, P, P, F, I, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_stats_tile_m": [I, I, I, I, I, I, I],
+    "ssp_conv_workspace_floats": [I, I, I, I, I, I, I],
+    "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
     "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],
     "ssp_bn_eval_prepare": [I, P, P, P, P, F, P, P, P, P, P],

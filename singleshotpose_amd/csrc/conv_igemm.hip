@@ -360,14 +360,8 @@ static int launch_cfg(ConvArgs a, hipStream_t stream, int extra_lds = 0) {
   dim3 grid(a.ntile_m * a.ntile_n * a.ksplit), block(WM * WN * 64);
   const int lds_bytes = 3 * (BM + BN) * (BK + 4) * 4 + extra_lds;
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, ABL, PASS>;
-  static int configured = 0;   // per instantiation
-  if (lds_bytes > configured) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
-      ssp_set_error("conv_igemm: cannot reserve %d bytes of LDS", lds_bytes);
-      return SSP_ERR_HIP;
-    }
-    configured = lds_bytes;
-  }
+  static SspKernelCache cache;   // per instantiation, per device
+  if (int rc = ssp_kernel_prepare((const void*)kern, lds_bytes, WM * WN * 64, &cache, nullptr, "conv_igemm")) return rc;
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_igemm");
   return SSP_OK;
@@ -383,16 +377,17 @@ int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int i
 // mid-size grids use 64-row tiles instead.
 struct IgemmPlan { int bm, ksplit, slots, tail; };   // slots: LDS ring depth of the LDS-direct kernel (0 = its default);
                                                       // tail: K split of the last partial wave's tiles (hybrid launch), 0 = off
-static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
+static IgemmPlan select_plan(int M, int Cin, int Cout, int R, int plan_code) {
   IgemmPlan pl = {256, 1, 0, 0};
   if (Cout <= 64) {
     if (Cout > 32 && Cin % 16 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50) pl.bm = 128;   // 128x64 LDS-direct tiles
     return pl;
   }
   pl.bm = 128;
-  // explicit plan (engine autotuner: "igemm_plan" = tail*100000 + bm*100 + ksplit*10 + slots); invalid requests fall
-  // back to auto
-  const int forced = ssp_option(SSP_OPT_IGEMM_PLAN);
+  // explicit plan (the `plan` argument of the entry points, chosen per launch shape by the engine's autotuner:
+  // tail*100000 + bm*100 + ksplit*10 + slots); 0 = this heuristic.  The process-wide "igemm_plan" knob only stands in
+  // when the caller passed 0 (bench / tools experiments).  Invalid requests fall back to auto.
+  const int forced = plan_code > 0 ? plan_code : ssp_option(SSP_OPT_IGEMM_PLAN);
   if (forced > 0) {
     const int ftail = forced / 100000, fbm = (forced / 100) % 1000, fks = (forced / 10) % 10, fsl = forced % 10;
     const int niter16 = (Cin % 16 == 0) ? R * R * (Cin / 16) : 0;
@@ -427,16 +422,17 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R) {
   }
   return pl;
 }
-int ssp_conv_tile_m(int M, int Cin, int Cout, int R) { return select_plan(M, Cin, Cout, R).bm; }
-int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R) {
-  IgemmPlan pl = select_plan(M, Cin, Cout, R);
+int ssp_conv_tile_m(int M, int Cin, int Cout, int R, int plan) { return select_plan(M, Cin, Cout, R, plan).bm; }
+int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan) {
+  IgemmPlan pl = select_plan(M, Cin, Cout, R, plan);
   const int deepest = pl.ksplit > pl.tail ? pl.ksplit : pl.tail;      // a hybrid launch parks at most M rows x tail
   return deepest > 1 ? (int64_t)deepest * M * Cout : 0;
 }
 
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
-                          int64_t ws_floats, int prof_kind, hipStream_t stream, const float* escale, float act_slope) {
+                          int64_t ws_floats, int plan, int prof_kind, hipStream_t stream, const float* escale,
+                          float act_slope) {
   SSP_CHECK_ARG(R == 1 || R == 3, "conv: only 1x1 and 3x3 filters are supported (got %d)", R);
   SSP_CHECK_ARG(Cin % 4 == 0 && Cin > 0, "conv: Cin must be a positive multiple of 4 (got %d)", Cin);
   SSP_CHECK_ARG(ldin % 4 == 0 && ldin >= Cin, "conv: ldin must be a multiple of 4 and >= Cin");
@@ -450,7 +446,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   a.probe = 0;
   a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;
-  const IgemmPlan pl = select_plan(a.M, Cin, Cout, R);
+  const IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
   a.ksplit = pl.ksplit;
   a.ws = ws;
   if (pl.ksplit > 1)

@@ -284,19 +284,9 @@ static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   const int lds_bytes = NSLOT * (BM + BN) * 64 + ((BN % 64) ? 1024 : 0);
   auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT, WM, WN>;
-  static int configured = 0;
-  static int slots = 0;       // workgroups resident on the whole chip at once
-  if (lds_bytes > configured) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
-      ssp_set_error("conv_igemm_dma: cannot reserve %d bytes of LDS", lds_bytes);
-      return SSP_ERR_HIP;
-    }
-    configured = lds_bytes;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds_bytes) != hipSuccess || per_cu < 1)
-      per_cu = 2;
-    slots = per_cu * 256;
-  }
+  static SspKernelCache cache;   // per instantiation, per device
+  int slots = 0;                 // workgroups resident on the whole chip at once
+  if (int rc = ssp_kernel_prepare((const void*)kern, lds_bytes, 256, &cache, &slots, "conv_igemm_dma")) return rc;
   a.col_major = ((int64_t)a.R * a.R * a.Cin * a.Cout * 4 >= (4ll << 20) && a.ntile_n > 1 &&
                  ssp_option(SSP_OPT_IGEMM_VARIANT) != 80) ? 1 : 0;
   // hybrid launch: as many whole resident waves of un-split tiles as fit, the rest of the tiles split tail_ks ways

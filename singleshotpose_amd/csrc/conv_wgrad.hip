@@ -321,19 +321,9 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
   const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * a.R * a.R;
   const int lds_bytes = 3 * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_kernel<BMO, BNI, WM, WN, WK>;
-  static int configured = 0;
-  static int slots = 0;   // workgroups resident on the whole chip (occupancy x 256 CUs)
-  if (lds_bytes > configured) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
-      ssp_set_error("conv_wgrad: cannot reserve %d bytes of LDS", lds_bytes);
-      return SSP_ERR_HIP;
-    }
-    configured = lds_bytes;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds_bytes) != hipSuccess || per_cu < 1)
-      per_cu = 2;
-    slots = per_cu * 256;
-  }
+  static SspKernelCache cache;   // per instantiation, per device
+  int slots = 0;                 // workgroups resident on the whole chip (occupancy x CUs)
+  if (int rc = ssp_kernel_prepare((const void*)kern, lds_bytes, 256, &cache, &slots, "conv_wgrad")) return rc;
   // Split the pixel reduction so that the grid is (close to) a whole number of resident waves of workgroups - a
   // 2.25-wave grid runs as long as a 3-wave one - with 2..5 waves in total and >= 8 staged chunks per workgroup.
   const int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);

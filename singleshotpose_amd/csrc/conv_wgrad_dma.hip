@@ -332,19 +332,9 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold);
   const int lds_bytes = NSLOT * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>;
-  static int configured = 0;
-  static int slots = 0;
-  if (lds_bytes > configured) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
-      ssp_set_error("conv_wgrad_dma: cannot reserve %d bytes of LDS", lds_bytes);
-      return SSP_ERR_HIP;
-    }
-    configured = lds_bytes;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds_bytes) != hipSuccess || per_cu < 1)
-      per_cu = 2;
-    slots = per_cu * 256;
-  }
+  static SspKernelCache cache;   // per instantiation, per device
+  int slots = 0;
+  if (int rc = ssp_kernel_prepare((const void*)kern, lds_bytes, 256, &cache, &slots, "conv_wgrad_dma")) return rc;
   // Split over pixels.  Every workgroup ends with BMO x BNI atomics onto its filter tile, and all workgroups of a tile
   // hit the same lines: on the layers with few tiles (layers 4-16: 9-72 tiles) the atomic traffic is 5-12 % of the
   // launch, so the split is the SMALLEST one that fills whole resident waves of workgroups (>= 93 % of the last wave),

@@ -287,6 +287,10 @@ __global__ void __launch_bounds__(256) region_decode_argmax_kernel(const float* 
   }
   if (tid == 0) {
     int key = sk[0];
+    // every confidence NaN (a diverged network): no cell ever compared greater, the key is still the sentinel.  Decode
+    // cell 0 (in bounds) and leave conf = -inf in the last slot: the host raises, as the reference does (utils.py:296
+    // returns a `box` that was never bound)
+    if ((unsigned)key >= (unsigned)ncell) key = 0;
     int an = key % nA, rem = key / nA;
     int j = rem / nW, i = rem % nW;
     int64_t base = ((int64_t)(b * nA + an) * nCh) * hw + rem;

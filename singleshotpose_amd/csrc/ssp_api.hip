@@ -8,12 +8,12 @@
 #include "ssp_common.h"
 
 // ---- kernels' host launchers (defined next to the kernels) ----
-int ssp_conv_tile_m(int M, int Cin, int Cout, int R);
-int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R);
+int ssp_conv_tile_m(int M, int Cin, int Cout, int R, int plan);
+int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan);
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
-                          int64_t ws_floats, int prof_kind, hipStream_t stream, const float* escale = nullptr,
-                          float act_slope = 1.f);
+                          int64_t ws_floats, int plan, int prof_kind, hipStream_t stream,
+                          const float* escale = nullptr, float act_slope = 1.f);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
@@ -74,6 +74,31 @@ static int g_options[SSP_OPT_COUNT] = {1, 0, 0, 0};
 static const char* g_option_names[SSP_OPT_COUNT] = {"igemm_xcd", "igemm_variant", "wgrad_variant", "igemm_plan"};
 int ssp_option(int which) { return g_options[which]; }
 
+// ---- per-device kernel configuration cache ----
+static std::mutex g_kernel_mu;
+int ssp_kernel_prepare(const void* kern, int lds_bytes, int threads, SspKernelCache* cache, int* slots, const char* name) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SSP_MAX_DEVICES) {
+    ssp_set_error("%s: no current HIP device (or device index >= %d)", name, SSP_MAX_DEVICES);
+    return SSP_ERR_HIP;
+  }
+  std::lock_guard<std::mutex> lk(g_kernel_mu);
+  if (lds_bytes > cache->configured[dev]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      ssp_set_error("%s: cannot reserve %d bytes of LDS", name, lds_bytes);
+      return SSP_ERR_HIP;
+    }
+    int per_cu = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 2;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+    cache->slots[dev] = per_cu * ncu;
+    cache->configured[dev] = lds_bytes;
+  }
+  if (slots != nullptr) *slots = cache->slots[dev];
+  return SSP_OK;
+}
+
 // ---- launch timer ----
 namespace {
 struct ProfRec {
@@ -113,7 +138,7 @@ SspProfScope::~SspProfScope() {
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err; }
-int ssp_abi_version(void) { return 1; }
+int ssp_abi_version(void) { return 2; }
 int ssp_set_option(const char* name, int value) {
   for (int i = 0; i < SSP_OPT_COUNT; ++i)
     if (name != nullptr && strcmp(name, g_option_names[i]) == 0) {
@@ -125,28 +150,29 @@ int ssp_set_option(const char* name, int value) {
 }
 
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
-                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* workspace,
+                 int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int plan, float* workspace,
                  int64_t workspace_floats, void* stream) {
   return ssp_conv_igemm_launch(in, wt, out, bias, stats, B, H, W, Cin, Cout, ldin, ldout, R, accumulate, workspace,
-                               workspace_floats, SSP_PROF_CONV_FWD, (hipStream_t)stream);
+                               workspace_floats, plan, SSP_PROF_CONV_FWD, (hipStream_t)stream);
 }
 int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const float* scale, const float* shift,
-                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R,
+                        float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R, int plan,
                         float* workspace, int64_t workspace_floats, void* stream) {
   return ssp_conv_igemm_launch(in, wt, out, shift, nullptr, B, H, W, Cin, Cout, ldin, ldout, R, 0, workspace,
-                               workspace_floats, SSP_PROF_CONV_FWD, (hipStream_t)stream, scale, slope);
+                               workspace_floats, plan, SSP_PROF_CONV_FWD, (hipStream_t)stream, scale, slope);
 }
-int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R) {
-  return ssp_conv_tile_m(B * H * W, Cin, Cout, R);
+int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  return ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan);
 }
-int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R) {
-  return ssp_conv_ws_floats(B * H * W, Cin, Cout, R);
+int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  return ssp_conv_ws_floats(B * H * W, Cin, Cout, R, plan);
 }
 
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
-                   int lddx, int R, int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
+                   int lddx, int R, int accumulate, int plan, float* workspace, int64_t workspace_floats,
+                   void* stream) {
   return ssp_conv_igemm_launch(dy, wt, dx, nullptr, nullptr, B, H, W, Cout_dy, Cin_dx, lddy, lddx, R, accumulate,
-                               workspace, workspace_floats, SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
+                               workspace, workspace_floats, plan, SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
 }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,

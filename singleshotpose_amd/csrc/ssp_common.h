@@ -57,6 +57,17 @@ struct SspProfScope {
 enum SspOption { SSP_OPT_IGEMM_XCD = 0, SSP_OPT_IGEMM_VARIANT = 1, SSP_OPT_WGRAD_VARIANT = 2, SSP_OPT_IGEMM_PLAN = 3, SSP_OPT_COUNT = 4 };
 int ssp_option(int which);
 
+// Per-device cache of one kernel instantiation's dynamic-LDS reservation and chip-wide resident-workgroup count
+// (the only mutable state the library keeps besides the experiment knobs): filled under a mutex, one entry per HIP
+// device so that several devices driven from one process each get their hipFuncSetAttribute call.
+#define SSP_MAX_DEVICES 16
+struct SspKernelCache {
+  int configured[SSP_MAX_DEVICES];   // bytes of dynamic LDS the kernel was last configured for on that device
+  int slots[SSP_MAX_DEVICES];        // workgroups resident on the whole chip at that size
+};
+// Returns SSP_OK and the resident-workgroup count in *slots (may be nullptr); configures the kernel on first use.
+int ssp_kernel_prepare(const void* kern, int lds_bytes, int threads, SspKernelCache* cache, int* slots, const char* name);
+
 static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Observed dispatch places workgroup b on XCD b%8 (MI355X_MICROARCH.md, "Workgroup dispatch").

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from .cfg import (load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, resolve_layers, save_conv, save_conv_bn,
                   save_fc)
-from .engine import Plan, _DarknetFn, weights_changed
+from .engine import Plan, _DarknetEvalFn, _DarknetFn, weights_changed
 from .region_loss import RegionLoss, RegionLossMulti
 
 
@@ -78,6 +78,7 @@ class Darknet(nn.Module):
         self.seen = 0
         self.iter = 0
         self._plans = collections.OrderedDict()
+        self._bn_epoch = 0          # bumped by every training-mode forward (engine.Plan: inference BN constants key)
         self._max_plans = 32
         # eval forward as one captured hipGraph replay (Plan.forward_graph).  Opt-in: measured no gain on MI355X - the
         # chain is not host-bound (B=1, 672x672: 1.04 ms eager, 36 launches x ~10 us of host time; 1.10 ms replayed)
@@ -243,8 +244,12 @@ class Darknet(nn.Module):
                 raise RuntimeError("model parameters are on %s but the input is on %s - call model.cuda()" % (p.device, x.device))
         plan = self._plan(shape, x.device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad and self.training:
+            return _DarknetFn.apply(plan, True, x, *params)
         if need_grad:
-            return _DarknetFn.apply(plan, self.training, x, *params)
+            # eval mode with autograd on (the reference's valid.py / test() never enter no_grad: their
+            # `Variable(data, volatile=True)` is a no-op today): inference-speed forward, backward by recomputation
+            return _DarknetEvalFn.apply(plan, x, *params)
         if self.graph_inference and not self.training:
             return plan.forward_graph(x)      # eval: the whole launch chain as one hipGraph replay
         return plan.forward(x, self.training)

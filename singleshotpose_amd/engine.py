@@ -30,6 +30,8 @@ _WEIGHTS_EPOCH = [0]
 # autotuned igemm plan per launch shape, shared by every Plan of the process: multi-scale training (dataset.py:66-90
 # draws a new resolution every 10 batches) revisits the same ~20 shapes, each is timed once
 _TUNE_CACHE = {}
+_TUNE_VERIFIED = set()         # launch shapes whose non-default plan passed verify-after-tune in this process
+TUNE_REJECTED = []             # (shape key, plan code) pairs verify-after-tune refused
 _TUNE_CACHE_FILE = [None]      # SSP_TUNE_CACHE=<json file>: loaded once, rewritten whenever a new shape was timed
 
 
@@ -241,13 +243,11 @@ class Plan(object):
         # statistics / split-K workspaces follow the (tuned or heuristic) plan of each launch
         for cs in self.convs.values():
             M = cs.M
-            _lib.call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
-            cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
-            cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k)
+            cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
+            cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
             if cs.bn:
                 cs.stats = torch.empty(cs.ntile * cs.cout * 2, **f32)
-        _lib.call('ssp_set_option', b'igemm_plan', 0)
         # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
         self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
@@ -302,15 +302,14 @@ class Plan(object):
                 self._autotune('dgrad')
             need = 1
             for cs in self.convs.values():
-                _lib.call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
                 cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
-                                                            cs.cin, cs.k)
+                                                            cs.cin, cs.k, cs.plan_dgrad)
                 need = max(need, cs.ws_dgrad)
-            _lib.call('ssp_set_option', b'igemm_plan', 0)
             if need > self.ws_floats:
                 torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
                 self.ws_floats = need
                 self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+                self._graph = None          # a captured inference chain holds the old workspace pointer
 
     def _repack_dgrad(self, cs, stream):
         src = cs.conv.weight.detach()
@@ -327,7 +326,13 @@ class Plan(object):
         input shape on the real buffers and keeps the fastest (per-shape tile selection).
         The library's shape heuristic is within ~5-15 % of the best choice on some layers; which plan wins depends on
         how the grid fills the 256 CUs.  One-off cost per (B,H,W): ~1 s for yolo-pose.cfg.  SSP_AUTOTUNE=0 disables;
-        SSP_TUNE_CACHE=<file> keeps the timed choices across processes (JSON)."""
+        SSP_TUNE_CACHE=<file> keeps the timed choices across processes (JSON).
+
+        Verify-after-tune: a non-default plan is admitted only after its output on seeded random operands agrees with the
+        default plan's output of the same launch (max|a-b| / max|b| <= 1e-5: the plans differ in fp32 summation order
+        only) and, for BN layers, after the batch statistics finalized from its per-tile partials agree too.  A code that
+        fails is refused (plan 0 runs) and reported in `engine.TUNE_REJECTED`.  Cached choices (this process or the JSON
+        file) are re-verified once per process."""
         B = self.B
         call = _lib.call
         st = torch.cuda.current_stream().cuda_stream
@@ -346,9 +351,12 @@ class Plan(object):
         max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
         stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32) if which == 'fwd' else None
-        gscratch = torch.empty(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32) if which == 'dgrad' else None
+        gscratch = torch.zeros(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32) if which == 'dgrad' else None
+        verify = os.environ.get('SSP_TUNE_VERIFY', '1') != '0'
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(1234)
 
-        def best_of(launch, cout, mn, key):
+        def best_of(launch, mn, key):
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
                 return _TUNE_CACHE[key]
             best, best_t = 0, None
@@ -358,14 +366,13 @@ class Plan(object):
             for code in cands + deep:
                 if ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
-                call('ssp_set_option', b'igemm_plan', code)
                 try:
-                    launch()
+                    launch(code)
                     ts = []
                     for _ in range(2):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        launch()
+                        launch(code)
                         e1.record()
                         e1.synchronize()
                         ts.append(e0.elapsed_time(e1))
@@ -377,22 +384,67 @@ class Plan(object):
             _TUNE_CACHE[key] = best
             return best
 
+        def admitted(code, key, launch, out_of, operands, bn_of=None):
+            """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands."""
+            if code == 0 or not verify or key in _TUNE_VERIFIED:
+                return code
+            for t in operands:
+                t.uniform_(-1.0, 1.0, generator=gen)
+            res = []
+            for c in (0, code):
+                launch(c)
+                r = [out_of().clone()]
+                if bn_of is not None:
+                    r += bn_of(c)
+                res.append(r)
+            ok = True
+            for a, b in zip(res[0], res[1]):
+                den = float(a.abs().max())
+                err = float((a - b).abs().max())
+                if not (err <= 1e-5 * max(den, 1e-30)):      # also false for NaN
+                    ok = False
+            if ok:
+                _TUNE_VERIFIED.add(key)
+                return code
+            TUNE_REJECTED.append((key, code))
+            _TUNE_CACHE[key] = 0
+            return 0
+
         for cs in elig:
             if which == 'fwd' and cs.cout > 64:
                 # operand contents are irrelevant for timing: a channels-last-sized parameter stands in for itself
                 wop = cs.conv.weight if cs.cinp == cs.cin else self._wbuf(cs)
-                cs.plan_fwd = best_of(lambda: call('ssp_conv_fwd', cs.inp.ptr, wop.data_ptr(), cs.raw.data_ptr(),
-                                                   None, stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp,
-                                                   cs.cout, cs.inp.ld, cs.ldraw, cs.k, 0, ws.data_ptr(), max_ws, st),
-                                      cs.cout, cs.M * cs.coutp,
-                                      ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn)))
+                key = ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn))
+
+                def launch(code, cs=cs, wop=wop):
+                    call('ssp_conv_fwd', cs.inp.ptr, wop.data_ptr(), cs.raw.data_ptr(), None,
+                         stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
+                         cs.k, 0, code, ws.data_ptr(), max_ws, st)
+
+                def bn_of(code, cs=cs):
+                    # batch statistics from this plan's per-tile (mean, M2) partials: mean and 1/std per channel
+                    tm = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, code)
+                    tmp = torch.zeros(8, cs.coutp, **f32)
+                    tmp[0].fill_(1.0)
+                    tmp[3].fill_(1.0)
+                    call('ssp_bn_fwd_finalize', stats.data_ptr(), (cs.M + tm - 1) // tm, tm, cs.M, cs.cout,
+                         tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), tmp[3].data_ptr(), BN_MOMENTUM,
+                         BN_EPS, tmp[4].data_ptr(), tmp[5].data_ptr(), tmp[6].data_ptr(), tmp[7].data_ptr(), st)
+                    return [tmp[4, :cs.cout].clone(), tmp[5, :cs.cout].clone()]
+
+                code = best_of(launch, cs.M * cs.coutp, key)
+                cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [cs.inp.t] +
+                                       ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None)
             if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
-                cs.plan_dgrad = best_of(lambda: call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self._dpack, cs.doff),
-                                                     gscratch.data_ptr(), B, cs.H, cs.W, cs.coutp, cs.cin, cs.ldraw,
-                                                     cs.inp.ld, cs.k, 0, ws.data_ptr(), max_ws, st),
-                                        cs.cin, cs.M * cs.cinp,
-                                        ('dgrad', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld))
-        call('ssp_set_option', b'igemm_plan', 0)
+                key = ('dgrad', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld)
+                wslice = self._dpack[cs.doff:cs.doff + cs.cinp * cs.k * cs.k * cs.coutp]
+
+                def launch(code, cs=cs):
+                    call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self._dpack, cs.doff), gscratch.data_ptr(), B, cs.H,
+                         cs.W, cs.coutp, cs.cin, cs.ldraw, cs.inp.ld, cs.k, 0, code, ws.data_ptr(), max_ws, st)
+
+                code = best_of(launch, cs.M * cs.cinp, key)
+                cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld], [cs.raw, wslice])
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
@@ -459,6 +511,8 @@ class Plan(object):
         else:
             self.dgrad_ready = None
         waited = set()
+        if training:
+            self.net._bn_epoch += 1       # running statistics change below: every plan's inference constants are stale
         for op in self.ops_fwd:
             kind = op[0]
             if kind == 'conv':
@@ -474,25 +528,27 @@ class Plan(object):
                     # inference-mode BatchNorm is a per-channel affine map of constants: recomputed only when one of
                     # its four tensors changed (in-place updates bump _version; load_weights / fused SGD bump the epoch)
                     bn = cs.bnm
+                    # (a training-mode forward rewrites running_mean / running_var through raw pointers and reuses the
+                    # scale / shift vectors for the batch statistics: it bumps the net's BN epoch, also part of the key)
                     bkey = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean,
-                                                                     bn.running_var)) + (_WEIGHTS_EPOCH[0],)
+                                                                     bn.running_var)) + (_WEIGHTS_EPOCH[0],
+                                                                                         self.net._bn_epoch)
                     if inline_repack or self.bnversion.get(cs.ind) != bkey:
                         call('ssp_bn_eval_prepare', cs.cout, bn.weight.data_ptr(), bn.bias.data_ptr(),
                              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS, v[0].data_ptr(),
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
                         self.bnversion[cs.ind] = None if inline_repack else bkey
-                call('ssp_set_option', b'igemm_plan', cs.plan_fwd)
                 wptr = cs.conv.weight.data_ptr() if cs.packed else self._wbuf(cs).data_ptr()
                 if not training and not need_grad and cs.needs_act and not cs.pool and cs.coutp == cs.cout:
                     # inference, un-pooled block: BatchNorm affine + leaky folded into the conv epilogue - one launch,
                     # no raw-output round trip (backward needs the raw output, so training / autograd keep two steps)
                     call('ssp_conv_fwd_affine', cs.inp.ptr, wptr, cs.out.ptr, v[2].data_ptr() if cs.bn else None,
                          v[3].data_ptr() if cs.bn else bias, cs.slope, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld,
-                         cs.out.ld, cs.k, self.ws.data_ptr(), self.ws_floats, st)
+                         cs.out.ld, cs.k, cs.plan_fwd, self.ws.data_ptr(), self.ws_floats, st)
                     continue
                 call('ssp_conv_fwd', cs.inp.ptr, wptr, cs.raw.data_ptr(), bias,
                      cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
-                     cs.k, 0, self.ws.data_ptr(), self.ws_floats, st)
+                     cs.k, 0, cs.plan_fwd, self.ws.data_ptr(), self.ws_floats, st)
                 if cs.bn and training:
                     bn = cs.bnm
                     call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
@@ -683,9 +739,9 @@ class Plan(object):
                 if not cs.first:
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
-                    call('ssp_set_option', b'igemm_plan', cs.plan_dgrad)
                     call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
-                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, self.ws.data_ptr(), self.ws_floats, st)
+                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
+                         self.ws_floats, st)
                     written.add(src)
             elif t == 'maxpool':
                 if ind not in written:
@@ -747,6 +803,34 @@ class _DarknetFn(torch.autograd.Function):
                                "activations were overwritten")
         grads = plan.backward(grad_out.contiguous())
         res = [None, None, None]
+        for p in ctx.params:
+            res.append(grads.get(id(p)))
+        return tuple(res)
+
+
+class _DarknetEvalFn(torch.autograd.Function):
+    """Inference-mode forward with autograd enabled - what the reference's unchanged valid.py / train.py test() run:
+    `Variable(data, volatile=True)` (valid.py:113) is a no-op on current torch, so grad mode stays on.  The forward takes
+    the cheap inference chain (fused conv + BN affine + leaky launches, cached BN constants, no data-gradient operand
+    repacks); in the rare case that somebody does call backward on it (frozen-BN fine-tuning), backward first re-runs
+    the forward in its activation-keeping form and then the normal backward chain."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan = plan
+        ctx.params = params
+        ctx.x = x
+        ctx.xver = x._version
+        return plan.forward(x, False)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        if ctx.x._version != ctx.xver:
+            raise RuntimeError("Darknet (eval mode) backward: the input tensor was modified in place after the forward")
+        plan.forward(ctx.x, False, need_grad=True)      # recompute, keeping the raw conv outputs
+        grads = plan.backward(grad_out.contiguous())
+        res = [None, None]
         for p in ctx.params:
             res.append(grads.get(id(p)))
         return tuple(res)

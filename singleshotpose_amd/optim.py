@@ -98,6 +98,7 @@ class SGD(torch.optim.Optimizer):
             old = self.state.get(p, {}).get('momentum_buffer')
             if old is not None:
                 mv.copy_(old)
+                self._first = False      # momentum carried over (per-parameter steps or load_state_dict): not a first step
             p.data = pv
             self.state[p]['momentum_buffer'] = mv
             layout.append((p, off, n))
@@ -107,9 +108,13 @@ class SGD(torch.optim.Optimizer):
         if self._layout is None or len(items) != len(self._layout):
             return False
         base = self._flat_p.data_ptr()
+        mbase = self._flat_m.data_ptr()
         for (p, off), (q, qoff, n) in zip(items, self._layout):
             if p is not q or off != qoff or p.data_ptr() != base + 4 * off:
                 return False      # model.cuda()/load_state_dict replaced a tensor, or the plan's layout changed
+            m = self.state.get(p, {}).get('momentum_buffer')
+            if m is None or m.data_ptr() != mbase + 4 * off:
+                return False      # optimizer.load_state_dict() swapped the momentum tensors: re-adopt (copies them in)
         return True
 
     def _uniform_hyper(self):

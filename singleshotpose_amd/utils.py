@@ -58,17 +58,23 @@ def compute_transformation(points_3D, transformation):
 
 
 def calc_pts_diameter(pts):
-    """Largest pairwise distance of an (N,3) point set (utils.py:50-58), row-blocked instead of one row at a time."""
+    """Largest pairwise distance of an (N,3) point set (utils.py:50-58).
+
+    Same arithmetic as the reference, element for element: difference of the two points, square, sum over x,y,z, max,
+    one square root - so the result is bit-identical to its row-at-a-time loop (only blocked over rows).  On the GPU
+    box big meshes (valid.py:72 passes the 5.8 k vertices of the object model) go through ssp_pts_diameter, which is
+    pinned bit-exact to the same golden value (tests/test_gpu_head.py)."""
     pts = np.asarray(pts)
-    best = -1.0
     n = pts.shape[0]
-    step = max(1, (1 << 22) // max(n, 1))
-    sq = (pts * pts).sum(axis=1)
+    if n >= 1024 and pts.dtype == np.float64 and torch.cuda.is_available():
+        return calc_pts_diameter_gpu(pts)
+    best = -1
+    step = max(1, (1 << 21) // max(n, 1))
     for i in range(0, n, step):
-        blk = pts[i:i + step]
-        d2 = sq[i:i + step, None] + sq[None, :] - 2.0 * blk.dot(pts.T)
-        best = max(best, float(d2.max()))
-    return math.sqrt(max(best, 0.0))
+        diff = pts[i:i + step, None, :] - pts[None, :, :]
+        d2 = (diff * diff).sum(axis=2).max()
+        best = max(best, d2)
+    return math.sqrt(best) if n else -1
 
 
 def adi(pts_est, pts_gt):
@@ -233,6 +239,9 @@ def convert2cpu_long(gpu_matrix):
     return torch.LongTensor(gpu_matrix.size()).copy_(gpu_matrix)
 
 
+_BOX_PINNED = {}
+
+
 def region_boxes_batched(output, num_classes, num_keypoints, num_anchors=1, only_objectness=1):
     """Per-image best cell: (B, 2K+4) device tensor {2K coords, det_conf, cls_max_conf, cls_max_id, conf}."""
     if output.dim() == 3:
@@ -255,14 +264,29 @@ def get_region_boxes(output, num_classes, num_keypoints, only_objectness=1, vali
     larger than every earlier one (utils.py:262-288).  The per-image arg-max runs on the GPU; picking the first
     best image is a B-element host step after the single device->host copy.
     """
-    boxes = region_boxes_batched(output, num_classes, num_keypoints, 1, only_objectness).cpu()
+    dev_boxes = region_boxes_batched(output, num_classes, num_keypoints, 1, only_objectness)
+    # one device->host copy of B x (2K+4) floats into a cached pinned buffer (88 bytes for valid.py's batch of 1)
+    key = (tuple(dev_boxes.shape), dev_boxes.device.index)
+    host = _BOX_PINNED.get(key)
+    if host is None:
+        if len(_BOX_PINNED) > 8:
+            _BOX_PINNED.clear()
+        host = _BOX_PINNED[key] = torch.empty(dev_boxes.shape, dtype=torch.float32).pin_memory()
+    host.copy_(dev_boxes, non_blocking=True)
+    torch.cuda.current_stream(dev_boxes.device).synchronize()
     K = num_keypoints
+    confs = host[:, 2 * K + 3].tolist()
     best = 0
-    for b in range(1, boxes.size(0)):
-        if boxes[b, 2 * K + 3] > boxes[best, 2 * K + 3]:
+    for b in range(1, len(confs)):
+        if confs[b] > confs[best]:
             best = b
-    row = boxes[best]
-    box = [row[i].clone() for i in range(2 * K + 2)]
+    if not confs[best] > -sys.maxsize:
+        # no confidence compared greater than the reference's -sys.maxsize start value (every one NaN: a diverged
+        # network): the reference's loop never binds `box` and its `return box` raises this (utils.py:229,262-296)
+        raise UnboundLocalError("local variable 'box' referenced before assignment (get_region_boxes: no cell has a "
+                                "confidence > -sys.maxsize; the network output is NaN)")
+    row = host[best].clone()
+    box = list(row[:2 * K + 2].unbind(0))
     box.append(row[2 * K + 2].long())
     return box
 

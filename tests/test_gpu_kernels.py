@@ -52,13 +52,13 @@ def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
     wd = G.pack_fwd(w, cinp)
     out = torch.full((B * H * W, ldout), float('nan'), dtype=torch.float32, device=G.dev())
     bd = bvec.to(G.dev()) if bias else None
-    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, cinp, Cout, R)
-    wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R))
+    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, cinp, Cout, R, 0)
+    wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R, 0))
     ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
     ntile = (B * H * W + tile_m - 1) // tile_m
     stats = torch.zeros(ntile * Cout * 2, dtype=torch.float32, device=G.dev())
     _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
-              stats.data_ptr(), B, H, W, cinp, Cout, ldin, ldout, R, 0, ws.data_ptr(), wsn, G.stream())
+              stats.data_ptr(), B, H, W, cinp, Cout, ldin, ldout, R, 0, 0, ws.data_ptr(), wsn, G.stream())
     torch.cuda.synchronize()
     got = G.from_nhwc(out, B, Cout, H, W, xout_off)
     assert rel_err(got.numpy(), ref.numpy()) < TOL
@@ -68,7 +68,7 @@ def test_conv_fwd(B, H, W, Cin, Cout, R, xin, xout, bias):
         assert torch.isnan(o[:, :xout_off]).all() and torch.isnan(o[:, xout_off + Cout:]).all()
     # accumulate mode
     _lib.call('ssp_conv_fwd', G.p(xd, xin_off), wd.data_ptr(), G.p(out, xout_off), bd.data_ptr() if bias else None,
-              None, B, H, W, cinp, Cout, ldin, ldout, R, 1, ws.data_ptr(), wsn, G.stream())
+              None, B, H, W, cinp, Cout, ldin, ldout, R, 1, 0, ws.data_ptr(), wsn, G.stream())
     torch.cuda.synchronize()
     got2 = G.from_nhwc(out, B, Cout, H, W, xout_off)
     assert rel_err(got2.numpy(), (2 * ref).numpy()) < TOL
@@ -139,9 +139,9 @@ def test_conv_dgrad_wgrad(B, H, W, Cin, Cout, R):
     if Cin % 4 == 0:
         wd = G.pack_dgrad(w.detach(), coutp)
         dx = torch.full((B * H * W, Cin), float('nan'), dtype=torch.float32, device=G.dev())
-        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R))
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, 0))
         ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
-        _lib.call('ssp_conv_dgrad', dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin, coutp, Cin, R, 0, ws.data_ptr(), wsn, G.stream())
+        _lib.call('ssp_conv_dgrad', dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin, coutp, Cin, R, 0, 0, ws.data_ptr(), wsn, G.stream())
         torch.cuda.synchronize()
         assert rel_err(G.from_nhwc(dx, B, Cin, H, W).numpy(), x.grad.numpy()) < TOL
 
@@ -294,7 +294,7 @@ def test_colsum():
 def test_error_reporting():
     G, _lib = _imports()
     with pytest.raises(_lib.SspError, match="1x1 and 3x3"):
-        _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, None, 0, G.stream())
+        _lib.call('ssp_conv_fwd', None, None, None, None, None, 1, 4, 4, 4, 4, 4, 4, 5, 0, 0, None, 0, G.stream())
 
 
 @pytest.mark.parametrize("B,H,W,C,Cp,ld", [(2, 32, 32, 3, 4, 4), (1, 5, 7, 3, 4, 4), (1, 3, 3, 1, 4, 8), (2, 4, 6, 4, 4, 4),
@@ -339,16 +339,12 @@ def test_conv_fwd_affine_eval_block(B, H, W, Cin, Cout, R, plan, slope, with_sca
     xp[:, :Cin] = x
     xd, wd = G.to_nhwc(xp), G.pack_fwd(w, cinp)
     out = torch.full((B * H * W, Cout), float('nan'), dtype=torch.float32, device=G.dev())
-    _lib.call('ssp_set_option', b'igemm_plan', plan)
-    try:
-        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R))
-        ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
-        sd, hd = scale.to(G.dev()), shift.to(G.dev())
-        _lib.call('ssp_conv_fwd_affine', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), sd.data_ptr() if with_scale else None,
-                  hd.data_ptr(), slope, B, H, W, cinp, Cout, cinp, Cout, R, ws.data_ptr(), wsn, G.stream())
-        torch.cuda.synchronize()
-    finally:
-        _lib.call('ssp_set_option', b'igemm_plan', 0)
+    wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, cinp, Cout, R, plan))
+    ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+    sd, hd = scale.to(G.dev()), shift.to(G.dev())
+    _lib.call('ssp_conv_fwd_affine', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), sd.data_ptr() if with_scale else None,
+              hd.data_ptr(), slope, B, H, W, cinp, Cout, cinp, Cout, R, plan, ws.data_ptr(), wsn, G.stream())
+    torch.cuda.synchronize()
     assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
 
 
@@ -366,23 +362,19 @@ def test_conv_hybrid_launch_matches_plain(plan):
     M = B * H * W
 
     def run(code, accumulate_twice=False):
-        _lib.call('ssp_set_option', b'igemm_plan', code)
-        try:
-            tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, R)
-            wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R))
-            ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
-            ntile = (M + tile_m - 1) // tile_m
-            stats = torch.full((ntile * Cout * 2,), float('nan'), dtype=torch.float32, device=G.dev())
-            out = torch.zeros(M, Cout, dtype=torch.float32, device=G.dev())
-            _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, stats.data_ptr(), B, H, W, Cin,
-                      Cout, Cin, Cout, R, 0, ws.data_ptr(), wsn, G.stream())
-            if accumulate_twice:
-                _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout,
-                          Cin, Cout, R, 1, ws.data_ptr(), wsn, G.stream())
-            torch.cuda.synchronize()
-            return out.cpu().numpy(), stats.cpu().numpy().reshape(ntile, Cout, 2), tile_m, wsn
-        finally:
-            _lib.call('ssp_set_option', b'igemm_plan', 0)
+        tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, R, code)
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, code))
+        ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+        ntile = (M + tile_m - 1) // tile_m
+        stats = torch.full((ntile * Cout * 2,), float('nan'), dtype=torch.float32, device=G.dev())
+        out = torch.zeros(M, Cout, dtype=torch.float32, device=G.dev())
+        _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, stats.data_ptr(), B, H, W, Cin,
+                  Cout, Cin, Cout, R, 0, code, ws.data_ptr(), wsn, G.stream())
+        if accumulate_twice:
+            _lib.call('ssp_conv_fwd', xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout,
+                      Cin, Cout, R, 1, code, ws.data_ptr(), wsn, G.stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), stats.cpu().numpy().reshape(ntile, Cout, 2), tile_m, wsn
     base = plan % 100000
     o_plain, s_plain, tm_plain, ws_plain = run(base)
     o_hyb, s_hyb, tm_hyb, ws_hyb = run(plan)

@@ -65,13 +65,13 @@ def run_cases(args, dev, st, B):
         dw = torch.zeros(Cout * R * R * Cin, device=dev)
         stats = torch.empty(((M + 63) // 64) * Cout * 2, device=dev)  # sized for the smallest M tile any variant uses
         flop = 2.0 * M * Cout * R * R * Cin
-        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R))
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, 0), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, 0))
         ws = torch.empty(wsn, device=dev)
         fns = {
             'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
-                                     B, H, W, Cin, Cout, Cin, coutp, R, 0, ws.data_ptr(), wsn, st),
+                                     B, H, W, Cin, Cout, Cin, coutp, R, 0, 0, ws.data_ptr(), wsn, st),
             'dgrad': lambda: _lib.call('ssp_conv_dgrad', dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin,
-                                       coutp, Cin, R, 0, ws.data_ptr(), wsn, st),
+                                       coutp, Cin, R, 0, 0, ws.data_ptr(), wsn, st),
             'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
                                        coutp, Cin, R, st),
         }
