@@ -40,8 +40,12 @@ def synthetic_batch(B, H, W, seed, device):
     return x.to(device), t.view(B, -1)   # labels stay on the host (float64), as train.py:83 leaves them
 
 
-def cpu_baseline(cfgfile, B, H, W, budget_s=25.0):
-    """The same step on the CPU oracle (reference semantics, PyTorch-CPU kernels): forward, RegionLoss, backward."""
+def cpu_baseline(cfgfile, B, H, W, budget_s=30.0):
+    """The same step on the CPU oracle (reference semantics, PyTorch-CPU kernels): forward, RegionLoss, backward.
+
+    A B = 8 step (the cfg's own batch, yolo-pose.cfg:3) does not scale to every hardware thread of a 2-socket host
+    (128 threads measured SLOWER than 8 in round 1): one warm-up + one timed step per thread count in {8, 16, 32, 64,
+    all}, then the best count is timed again (median of up to 3) and reported with the count that won."""
     from oracle.darknet_ref import forward_ref, seeded_state
     from oracle.region_loss_ref import region_loss_ref
     from singleshotpose_amd.cfg import parse_cfg
@@ -53,9 +57,8 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=25.0):
                 if not k.startswith('running'):
                     v.requires_grad_(True)
     x, tgt = synthetic_batch(B, H, W, 0, 'cpu')
-    times = []
-    t_begin = time.time()
-    for it in range(4):
+
+    def one_step():
         t0 = time.time()
         y = forward_ref(blocks, state, x, training=True)
         r = region_loss_ref(y.detach(), tgt, 20)
@@ -64,26 +67,50 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=25.0):
             if e is not None:
                 for v in e.values():
                     v.grad = None
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_begin > budget_s and times:
+        return time.time() - t0
+
+    all_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or all_threads
+    cands = sorted(set(t for t in (8, 16, 32, 64, all_threads) if t <= max(all_threads, 8)))
+    t_begin = time.time()
+    sweep = {}
+    for nt in cands:
+        torch.set_num_threads(nt)
+        one_step()                                  # warm-up at this thread count (oneDNN primitive caches)
+        sweep[nt] = one_step()
+        if time.time() - t_begin > budget_s:
             break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while len(times) < 3 and time.time() - t_begin < budget_s + 10:
+        times.append(one_step())
+    torch.set_num_threads(all_threads)
     med = float(np.median(times))
-    return {"value": round(B / med, 3), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d steps of fwd+RegionLoss+bwd at batch %d, %dx%d, after 1 warm-up (median)" % (len(times), B, H, W),
-            "host_cpus": os.cpu_count()}
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": int(best), "kind": "port", "batch": B,
+            "sample": "%d steps of fwd+RegionLoss+bwd at batch %d, %dx%d (median) with %d threads - the fastest of a "
+                      "one-step sweep over %s threads" % (len(times), B, H, W, best, sorted(sweep)),
+            "sweep_images_per_s": {str(k): round(B / v, 3) for k, v in sorted(sweep.items())},
+            "host_cpus": ncpu}
 
 
 def forward_traffic_per_launch():
     """HBM bytes per forward launch of the conv kernel, from the PMC passes committed under profiles/ (FETCH_SIZE
     doubled per MI355X_MICROARCH.md + WRITE_SIZE; tools/gpu_check.sh, tools/traffic_summary.py).  PMC counters cannot
-    be read from inside this process, so the figure is that of the last committed profile of this same command."""
+    be read from inside this process, so the figure is that of the last committed profile of this same command - and
+    only while the kernels are the ones that were profiled: the summary records a digest of singleshotpose_amd/csrc at
+    profile time, and a digest that no longer matches drops the figure (null) instead of reporting a stale one."""
     import glob
+    from singleshotpose_amd._lib import csrc_digest
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
     if not files:
         return None, None
     data = json.load(open(files[-1]))
+    src = os.path.relpath(files[-1], ROOT)
+    meta = data.pop('_meta', {})
+    if meta.get('csrc_sha1') != csrc_digest():
+        return None, "%s is stale: kernels changed since it was taken (csrc digest %s, now %s)" % (
+            src, str(meta.get('csrc_sha1'))[:10], csrc_digest()[:10])
     tot, n = 0.0, 0
     for name, v in data.items():
         # conv_igemm_dma_kernel<BM, BN, PASS, ...> and conv_igemm_kernel<BM, BN, WM, WN, BK, ABL, PASS> (first layer):
@@ -93,7 +120,85 @@ def forward_traffic_per_launch():
         if fwd:
             tot += v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch_reported'])
             n += v['launches']
-    return (round(tot / n) if n else None), os.path.relpath(files[-1], ROOT)
+    return (round(tot / n) if n else None), src
+
+
+def verify_step(model, crit, B, H, W, seed):
+    """One training step of THIS model on THIS batch against the CPU oracle (oracle/step_check.py), before anything is
+    timed: head / loss / running statistics vs an independent oracle forward, every conv launch vs the oracle's
+    convolution, parameter gradients vs the decision-frozen oracle backward.  The autotuned plans are the ones the timed
+    steps run.  Returns (verified, details)."""
+    from oracle.step_check import check_train_step
+    x_cpu, tgt = synthetic_batch(B, H, W, seed, 'cpu')
+    t0 = time.time()
+    r = check_train_step(model, crit, x_cpu, tgt, 20)
+    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 3e-4}
+    ok = all(r[k] < bars[k] for k in bars)
+    det = {k: float('%.3g' % r[k]) for k in bars}
+    det.update(bars={k: v for k, v in bars.items()}, seconds=round(time.time() - t0, 1),
+               tuned_plans=sum(1 for _, f, d in r['plans'] if f or d),
+               what="1 train step, batch %d, %dx%d, vs oracle/step_check.py (CPU, reference semantics)" % (B, H, W))
+    model.zero_grad(set_to_none=True)
+    return ok, det
+
+
+def extras(device, steps=5):
+    """Driver-record lines for BASELINE configs 4 and 5 (not the metric): the multi-object cfg's training step and the
+    inference path at valid.py's 672 x 672 operating point."""
+    from singleshotpose_amd.darknet import Darknet, DarknetMulti
+    from singleshotpose_amd.optim import SGD
+    from singleshotpose_amd.region_loss import RegionLossMulti
+    from singleshotpose_amd.utils import get_region_boxes
+    out = {}
+
+    def timed(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    torch.manual_seed(0)
+    B = 64
+    model = DarknetMulti(os.path.join(ROOT, 'cfg', 'yolo-pose-multi.cfg')).to(device).train()
+    crit = RegionLossMulti(num_keypoints=9, num_classes=13, anchors=model.anchors, num_anchors=5, pretrain_num_epochs=0)
+    crit.verbose = False
+    opt = SGD(model.parameters(), lr=1e-3 / B, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, 416, 416, generator=g).to(device)
+    t = torch.zeros(B, 50, 21, dtype=torch.float64)
+    for k in range(8):                      # 8 labels per image (1 object + 7 occluders, image_multi.py:8-36)
+        c = torch.rand(B, 2, generator=g, dtype=torch.float64) * 0.6 + 0.2
+        t[:, k, 0] = torch.randint(0, 13, (B,), generator=g).double()
+        t[:, k, 1:3] = c
+        t[:, k, 3:19] = (c[:, None, :] + (torch.rand(B, 8, 2, generator=g, dtype=torch.float64) - 0.5) * 0.24).reshape(B, 16)
+        t[:, k, 19:21] = torch.rand(B, 2, generator=g, dtype=torch.float64) * 0.3 + 0.1
+    tgt = t.view(B, -1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        crit(model(x), tgt, 1).backward()
+        opt.step()
+    dt = timed(step, steps)
+    out['multi_cfg_train_step'] = {"workload": "cfg/yolo-pose-multi.cfg train step, 416x416, batch 64, 8 labels/image",
+                                   "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1)}
+    del model, opt
+    torch.cuda.empty_cache()
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).to(device).eval()
+    with torch.no_grad():
+        for b, n in ((1, 30), (64, 5)):
+            xi = torch.rand(b, 3, 672, 672, generator=g).to(device)
+            dt = timed(lambda: model(xi), n, warm=3)
+            out['eval_672_b%d' % b] = {"workload": "cfg/yolo-pose.cfg eval forward, 672x672, batch %d" % b,
+                                        "ms": round(dt * 1e3, 4), "images_per_s": round(b / dt, 1)}
+            if b == 1:
+                y = model(xi)
+                dt = timed(lambda: get_region_boxes(y, 1, 9), 50, warm=5)
+                out['get_region_boxes_b1_us'] = round(dt * 1e6, 1)
+    return out
 
 
 def main():
@@ -105,6 +210,8 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--cfg', default=os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-verify', action='store_true', help='skip the one-step oracle check that runs before timing (N=1)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the multi-cfg / 672x672 inference lines (N=1)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--timers', default='conv', choices=['conv', 'all', 'none'],
                     help='launches bracketed by HIP events INSIDE the timed region: conv = forward conv launches only '
@@ -158,6 +265,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    verified, verify_detail = None, None
+    if world == 1 and not args.no_verify:
+        verified, verify_detail = verify_step(model, crit, B, H, W, 1000 + rank)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -245,7 +355,14 @@ def main():
             "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()},
             "final_loss": final_loss,
+            "verified": verified,
+            "verify": verify_detail,
         }
+        if world == 1 and not args.no_extras:
+            del opt, x
+            model._plans.clear()
+            torch.cuda.empty_cache()
+            res["extra"] = extras(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cfg, args.cpu_batch, H, W)
         print(json.dumps(res))

@@ -71,9 +71,17 @@ def reorg_ref(x, stride=2):
     return x.view(B, s * s * C, H // s, W // s)
 
 
-def forward_ref(blocks, state, x, training, momentum=0.1, keep=False):
+def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None):
     """Runs the layer list on CPU tensors.  `state` entries may require grad; running stats are updated in place
-    when training.  Returns the raw head (and every layer output when keep=True)."""
+    when training.  Returns the raw head (and every layer output when keep=True).
+
+    raw_override {layer index: (B,Cout,H,W) tensor}: decision-frozen mode.  The VALUE of that layer's convolution output
+    is replaced by the given tensor (the product's own raw conv output) while its gradient still flows into this
+    layer's convolution (straight-through: override + (conv - conv.detach()), the bracket is exactly 0).  Everything
+    downstream - batch statistics, leaky sign, max-pool arg-max - is then decided on identical numbers on both sides, so
+    whole-network gradients can be compared at a strict tolerance instead of the fp32-vs-fp64 envelope that independent
+    forward passes need (rounding flips max-pool / leaky decisions and the flips propagate).
+    raws (dict, optional): filled with this function's own convolution outputs {layer index: tensor (detached)}."""
     outputs = {}
     for ind, b in enumerate(blocks[1:]):
         t = b['type']
@@ -82,6 +90,10 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False):
             k = int(b['size'])
             pad = (k - 1) // 2 if int(b['pad']) else 0
             x = F.conv2d(x, e['weight'], e.get('bias'), stride=int(b['stride']), padding=pad)
+            if raws is not None:
+                raws[ind] = x.detach()
+            if raw_override is not None and ind in raw_override:
+                x = raw_override[ind] + (x - x.detach())
             if 'bn_weight' in e:
                 x = F.batch_norm(x, e['running_mean'], e['running_var'], e['bn_weight'], e['bn_bias'], training,
                                  momentum, 1e-4)

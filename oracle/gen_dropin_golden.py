@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Golden numbers for tests/test_gpu_dropin.py: the reference's UNMODIFIED valid.py and train.py, run on the CPU
+reference (oracle/run_reference_cpu.py) over the synthetic LINEMOD-shaped fixture (tests/fixture_linemod.py).
+
+Build container only:  python oracle/gen_dropin_golden.py      -> tests/golden/dropin_valid.json, dropin_train.json
+Also stages the reference's driver scripts for the GPU box (stage_callers): see its docstring.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import zipfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+CALLERS = ('valid.py', 'train.py', 'dataset.py', 'image.py', 'MeshPly.py')
+TRAIN_EPOCHS = 2
+
+
+def stage_callers():
+    """oracle/_ref/callers.zip <- the reference's driver scripts (valid.py, train.py) and the three helper modules they
+    import that are OUT of this repo's scope (dataset.py, image.py, MeshPly.py: the PIL data pipeline and the mesh
+    reader), byte for byte, so that the GPU box - which has no /root/reference - can EXECUTE the reference's unchanged
+    drivers against the drop-in.  Like a compiled oracle/_ref artefact: git-ignored (never enters history), not
+    gpurun-ignored (travels with the snapshot), rebuilt by __graft_entry__.build() whenever /root/reference is there.
+    darknet.py, region_loss.py, utils.py, cfg.py are deliberately NOT staged: those names resolve to dropin/."""
+    if not os.path.isdir(REF):
+        return None
+    dst = os.path.join(ROOT, 'oracle', '_ref')
+    os.makedirs(dst, exist_ok=True)
+    path = os.path.join(dst, 'callers.zip')
+    with zipfile.ZipFile(path, 'w', zipfile.ZIP_DEFLATED) as z:
+        for name in CALLERS:
+            z.write(os.path.join(REF, name), name)
+    return path
+
+
+def main():
+    import fixture_linemod as fx
+    stage_callers()
+    tmp = tempfile.mkdtemp(prefix='ssp_fixture_')
+    try:
+        fx.make(tmp, max_epochs=TRAIN_EPOCHS)
+        harness = os.path.join(ROOT, 'oracle', 'run_reference_cpu.py')
+        env = dict(os.environ)
+        env.pop('PYTHONPATH', None)
+        v = subprocess.run([sys.executable, harness, os.path.join(REF, 'valid.py'), '--datacfg', 'cfg/ape.data',
+                            '--modelcfg', 'cfg/yolo-pose.cfg', '--weightfile', 'init.weights'], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+        t = subprocess.run([sys.executable, harness, os.path.join(REF, 'train.py'), '--datacfg', 'cfg/ape.data',
+                            '--modelcfg', 'cfg/yolo-pose.cfg', '--initweightfile', 'init.weights'], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    meta = dict(generator='oracle/gen_dropin_golden.py', fixture='tests/fixture_linemod.py make(max_epochs=%d)' % TRAIN_EPOCHS,
+                pnp='oracle/pnp_ref.py (OpenCV ITERATIVE restated; cv2 itself is not installable here)')
+    rv = fx.parse_valid_output(v)
+    rv['_meta'] = dict(meta, script='/root/reference/valid.py (unmodified) on the CPU reference')
+    rt = fx.parse_train_output(t)
+    rt['_meta'] = dict(meta, script='/root/reference/train.py (unmodified) on the CPU reference, randomness pinned '
+                                    '(tools/run_pinned.py, seed 0)')
+    json.dump(rv, open(os.path.join(gold, 'dropin_valid.json'), 'w'), indent=1, sort_keys=True)
+    json.dump(rt, open(os.path.join(gold, 'dropin_train.json'), 'w'), indent=1, sort_keys=True)
+    print(json.dumps(rv, indent=1))
+    print(json.dumps(rt, indent=1))
+
+
+if __name__ == '__main__':
+    main()

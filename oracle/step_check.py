@@ -1,0 +1,145 @@
+"""Whole-training-step checker: the product's HIP step against the CPU oracle - TEST INFRASTRUCTURE ONLY.
+
+Used by tests/test_gpu_fullsize.py, __graft_entry__.smoke() and bench.py's --verify leg (outside every timed region).
+One call runs ONE training step of a product Darknet on the GPU (forward, RegionLoss, backward - what
+/root/reference/train.py:83-103 does per batch) and the same step on the oracle (oracle/darknet_ref.py,
+oracle/region_loss_ref.py: the reference's PyTorch-CPU semantics), from the same weights, batch and labels, and
+returns the error of every quantity the step produces:
+
+  head      max|a-b|/max|b| of the raw network output vs an independent oracle forward     (bar 1e-4)
+  loss      relative error of the RegionLoss value                                          (bar 1e-4)
+  running   worst max-normalised error of the BatchNorm running_mean / running_var updates  (bar 1e-4)
+  conv      worst per-layer error of the product's raw conv outputs vs the oracle's convolution of the product's
+            own layer inputs (layer-local, every conv launch of the step with the plan the autotuner picked)
+  grad      worst per-parameter max-normalised error of the parameter gradients against the DECISION-FROZEN oracle
+            backward (forward_ref(raw_override=...): the oracle's autograd runs on the product's own raw conv outputs,
+            so batch statistics, leaky signs and max-pool winners are decided on identical numbers; strict bar)
+  grad_out  error of dL/d(head) (the RegionLoss gradient) against the oracle's on the product's head
+
+SURVEY.md section 8(d) config 2 / config 5; tolerance north_star: fp32 conv / loss within 1e-4 relative.
+"""
+import numpy as np
+import torch
+
+from .darknet_ref import forward_ref
+from .region_loss_ref import region_loss_ref
+
+
+def _rel(a, b):
+    a = a.double()
+    b = b.double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def snapshot_state(model):
+    """Product module tree -> oracle state list (CPU clones), in block order."""
+    state = []
+    for ind, block in enumerate(model.blocks[1:]):
+        if block['type'] != 'convolutional':
+            state.append(None)
+            continue
+        seq = model.models[ind]
+        e = {'weight': seq[0].weight.detach().cpu().contiguous().clone()}
+        if int(block['batch_normalize']):
+            bn = seq[1]
+            e['bn_weight'] = bn.weight.detach().cpu().clone()
+            e['bn_bias'] = bn.bias.detach().cpu().clone()
+            e['running_mean'] = bn.running_mean.detach().cpu().clone()
+            e['running_var'] = bn.running_var.detach().cpu().clone()
+        else:
+            e['bias'] = seq[0].bias.detach().cpu().clone()
+        state.append(e)
+    return state
+
+
+def _clone(state, requires_grad=False):
+    out = []
+    for e in state:
+        if e is None:
+            out.append(None)
+            continue
+        d = {}
+        for k, v in e.items():
+            t = v.clone()
+            if requires_grad and not k.startswith('running'):
+                t.requires_grad_(True)
+            d[k] = t
+        out.append(d)
+    return out
+
+
+def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_backward=True):
+    """model: product Darknet on the GPU (train mode is set here); crit: product RegionLoss(Multi); x_cpu (B,3,H,W)
+    float32 CPU; tgt (B, 50*21) CPU labels.  Returns a dict of errors (see the module docstring) plus 'plans', the
+    (layer, forward plan code, dgrad plan code) triples that were active."""
+    loss_kwargs = dict(loss_kwargs or {})
+    dev = next(model.parameters()).device
+    state0 = snapshot_state(model)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    verbose, crit.verbose = crit.verbose, False
+    out = model(x_cpu.to(dev))
+    B, H, W = x_cpu.size(0), x_cpu.size(2), x_cpu.size(3)
+    plan = model._plans[(B, H, W, dev.index)]
+    # the product's raw conv outputs, NHWC [M][coutp] -> NCHW CPU (backward rewrites them in place: fetch now)
+    raws = {}
+    for ind, cs in plan.convs.items():
+        r = cs.raw.view(B, cs.H, cs.W, cs.ldraw)[..., :cs.cout].permute(0, 3, 1, 2)
+        raws[ind] = r.contiguous().cpu()
+    loss = crit(out, tgt, epoch)
+    loss.backward()
+    torch.cuda.synchronize()
+    crit.verbose = verbose
+    out_c = out.detach().cpu()
+    res = {'plans': [(ind, cs.plan_fwd, cs.plan_dgrad) for ind, cs in sorted(plan.convs.items())]}
+
+    # ---- independent oracle forward: head, loss, running statistics ----
+    st_a = _clone(state0)
+    with torch.no_grad():
+        y_ref = forward_ref(model.blocks, st_a, x_cpu, training=True)
+    r_ref = region_loss_ref(y_ref, tgt, epoch, **loss_kwargs)
+    res['head'] = _rel(out_c, y_ref)
+    res['loss'] = abs(float(loss) - r_ref['loss']) / max(abs(r_ref['loss']), 1e-30)
+    res['loss_gpu'], res['loss_ref'] = float(loss), r_ref['loss']
+    run = 0.0
+    for ind, e in enumerate(st_a):
+        if e is not None and 'running_mean' in e:
+            bn = model.models[ind][1]
+            run = max(run, _rel(bn.running_mean.cpu(), e['running_mean']), _rel(bn.running_var.cpu(), e['running_var']))
+    res['running'] = run
+    if not frozen_backward:
+        return res
+
+    # ---- decision-frozen oracle: per-layer conv check + whole-network gradients ----
+    st_b = _clone(state0, requires_grad=True)
+    own = {}
+    y_frozen = forward_ref(model.blocks, st_b, x_cpu, training=True, raw_override=raws, raws=own)
+    res['conv_by_layer'] = {ind: _rel(raws[ind], own[ind]) for ind in sorted(raws)}
+    res['conv'] = max(res['conv_by_layer'].values())
+    r_frz = region_loss_ref(out_c, tgt, epoch, **loss_kwargs)        # loss gradient on the product's own head
+    y_frozen.backward(r_frz['grad'])
+    # dL/d(head) of the product = gradient of the first backward node; recompute it through the product's loss
+    o2 = out.detach().clone().requires_grad_(True)
+    crit.verbose = False
+    crit(o2, tgt, epoch).backward()
+    crit.verbose = verbose
+    res['grad_out'] = _rel(o2.grad.cpu(), r_frz['grad'])
+    gerr = {}
+    for ind, e in enumerate(st_b):
+        if e is None:
+            continue
+        seq = model.models[ind]
+        gerr['%d.weight' % ind] = _rel(seq[0].weight.grad.cpu(), e['weight'].grad)
+        if 'bn_weight' in e:
+            gerr['%d.bn_weight' % ind] = _rel(seq[1].weight.grad.cpu(), e['bn_weight'].grad)
+            gerr['%d.bn_bias' % ind] = _rel(seq[1].bias.grad.cpu(), e['bn_bias'].grad)
+        else:
+            gerr['%d.bias' % ind] = _rel(seq[0].bias.grad.cpu(), e['bias'].grad)
+    res['grad_by_param'] = gerr
+    res['grad'] = max(gerr.values())
+    return res
+
+
+def summarize(res):
+    keys = [k for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad') if k in res]
+    return ', '.join('%s %.2e' % (k, res[k]) for k in keys)

@@ -66,6 +66,21 @@ _RET64 = ('ssp_conv_workspace_floats',)
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim")
 
 
+def csrc_digest():
+    """sha1 over the kernel sources (csrc/*.hip, *.h, include/ssp_hip.h): lets a profile artefact say which kernels it
+    measured (bench.py drops a traffic figure whose digest no longer matches)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.hip')) + glob.glob(os.path.join(_HERE, 'csrc', '*.h')))
+    files.append(os.path.join(os.path.dirname(_HERE), 'include', 'ssp_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fp:
+            h.update(fp.read())
+    return h.hexdigest()
+
+
 def exported_symbols():
     """Every entry point include/ssp_hip.h declares (used by the CPU-side ABI test)."""
     return ["ssp_last_error"] + list(_SIGS.keys())

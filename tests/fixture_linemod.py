@@ -1,0 +1,197 @@
+"""Synthetic LINEMOD-shaped mini dataset for driving the reference's own train.py / valid.py (TEST INFRASTRUCTURE).
+
+The reference ships no data, no weights and no meshes; LINEMOD and VOC are not downloadable
+here.  `make(root)` writes, deterministically (seeded numpy, PNG = lossless), everything the unmodified drivers open -
+laid out and formatted as README.md:96-130 / label_file_creation.md describe:
+
+  root/LINEMOD/ape/JPEGImages/0000NN.png   640 x 480 renders of a point-cloud object under a random pose
+  root/LINEMOD/ape/mask/00NN.png           object masks (image.py:126 derives this name from the image name)
+  root/LINEMOD/ape/labels/0000NN.txt       21 numbers: class, centroid, 8 projected box corners (/W, /H), x/y range
+  root/LINEMOD/ape/ape.ply                 ASCII mesh (MeshPly.py format: x y z nx ny nz r g b; faces)
+  root/LINEMOD/ape/train.txt, test.txt     image lists
+  root/VOCdevkit/VOC2012/JPEGImages/*.png  backgrounds for image.py:105-120
+  root/cfg/ape.data                        data cfg (intrinsics of cfg/ape.data:11-14)
+  root/cfg/yolo-pose.cfg                   the repo's cfg/yolo-pose.cfg with batch / max_epochs set for a 2-batch epoch
+  root/init.weights                        seeded .weights (oracle.darknet_ref.seeded_state, cfg.py:153-190 stream order)
+"""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 640, 480
+FX, FY, U0, V0 = 572.4114, 573.5704, 325.2611, 242.0489
+HALF = np.array([0.038, 0.039, 0.046])          # ape-sized half extents (metres)
+
+
+def _mesh(rs, n=1500):
+    """Points on an ellipsoid deformed by a few bumps; normals ~ radial."""
+    v = rs.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    bump = 1.0 + 0.15 * np.sin(5 * v[:, 0]) * np.cos(4 * v[:, 1])
+    pts = v * bump[:, None]
+    mn, mx = pts.min(axis=0), pts.max(axis=0)
+    pts = ((pts - mn) / (mx - mn) * 2.0 - 1.0) * HALF      # exact bounding box = +-HALF
+    col = np.clip(128 + 100 * v, 0, 255).astype(int)
+    return pts, v, col
+
+
+def _rodrigues(axis, angle):
+    axis = axis / np.linalg.norm(axis)
+    Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * Kx + (1 - np.cos(angle)) * Kx.dot(Kx)
+
+
+def _project(P, R, t):
+    c = P.dot(R.T) + t
+    return np.stack([FX * c[:, 0] / c[:, 2] + U0, FY * c[:, 1] / c[:, 2] + V0], 1), c[:, 2]
+
+
+def _corners():
+    mn, mx = -HALF, HALF
+    # utils.py:74-81 order: (min,min,min),(min,min,max),(min,max,min),(min,max,max),(max,min,min),...
+    return np.array([[(mx if a else mn)[0], (mx if b else mn)[1], (mx if c else mn)[2]]
+                     for a in (0, 1) for b in (0, 1) for c in (0, 1)])
+
+
+def _texture(rs, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 80 * np.sin(xx / rs.uniform(20, 60) + rs.uniform(0, 6)),
+                     128 + 80 * np.cos(yy / rs.uniform(20, 60) + rs.uniform(0, 6)),
+                     128 + 60 * np.sin((xx + yy) / rs.uniform(30, 90))], 2)
+    return np.clip(base + rs.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def make(root, n_train=16, n_test=8, batch=8, max_epochs=1, seed=0, weights_seed=31):
+    from PIL import Image
+    from oracle.darknet_ref import seeded_state, write_weights
+    from singleshotpose_amd.cfg import parse_cfg
+    rs = np.random.RandomState(seed)
+    d = os.path.join(root, 'LINEMOD', 'ape')
+    for sub in ('JPEGImages', 'mask', 'labels'):
+        os.makedirs(os.path.join(d, sub), exist_ok=True)
+    os.makedirs(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'cfg'), exist_ok=True)
+    pts, nrm, col = _mesh(rs)
+    with open(os.path.join(d, 'ape.ply'), 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                'property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\n'
+                'property uchar blue\nelement face 4\nproperty list uchar int vertex_indices\nend_header\n' % len(pts))
+        for p, n, c in zip(pts, nrm, col):
+            f.write('%.6f %.6f %.6f %.4f %.4f %.4f %d %d %d\n' % (p[0], p[1], p[2], n[0], n[1], n[2], c[0], c[1], c[2]))
+        for i in range(4):
+            f.write('3 %d %d %d\n' % (3 * i, 3 * i + 1, 3 * i + 2))
+    box = np.concatenate([np.zeros((1, 3)), _corners()], 0)           # centroid + 8 corners (valid.py:152)
+    names = []
+    for i in range(n_train + n_test):
+        R = _rodrigues(rs.standard_normal(3), rs.uniform(0, np.pi / 3))
+        t = np.array([rs.uniform(-0.1, 0.1), rs.uniform(-0.1, 0.1), rs.uniform(0.6, 1.2)])
+        img = _texture(rs, H, W)
+        mask = np.zeros((H, W, 3), np.uint8)
+        uv, z = _project(pts, R, t)
+        order = np.argsort(-z)                                       # far points first
+        shade = np.clip(0.4 + 0.6 * np.abs(nrm.dot(R.T)[:, 2]), 0, 1)
+        r = max(2, int(round(3.0 / t[2])))
+        for j in order:
+            x, y = int(round(uv[j, 0])), int(round(uv[j, 1]))
+            x0, x1, y0, y1 = max(x - r, 0), min(x + r + 1, W), max(y - r, 0), min(y + r + 1, H)
+            if x0 < x1 and y0 < y1:
+                img[y0:y1, x0:x1] = (col[j] * shade[j]).astype(np.uint8)
+                mask[y0:y1, x0:x1] = 255
+        name = '%06d' % i
+        Image.fromarray(img).save(os.path.join(d, 'JPEGImages', name + '.png'))
+        Image.fromarray(mask).save(os.path.join(d, 'mask', name[2:] + '.png'))
+        p2, _ = _project(box, R, t)
+        lab = [0.0]
+        for k in range(9):
+            lab += [p2[k, 0] / W, p2[k, 1] / H]
+        lab += [(p2[:, 0].max() - p2[:, 0].min()) / W, (p2[:, 1].max() - p2[:, 1].min()) / H]
+        with open(os.path.join(d, 'labels', name + '.txt'), 'w') as f:
+            f.write(' '.join('%.6f' % v for v in lab) + '\n')
+        names.append('LINEMOD/ape/JPEGImages/%s.png' % name)
+    with open(os.path.join(d, 'train.txt'), 'w') as f:
+        f.write('\n'.join(names[:n_train]) + '\n')
+    with open(os.path.join(d, 'test.txt'), 'w') as f:
+        f.write('\n'.join(names[n_train:]) + '\n')
+    for i in range(4):
+        Image.fromarray(_texture(rs, 375, 500)).save(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages', 'bg%d.png' % i))
+    with open(os.path.join(root, 'cfg', 'ape.data'), 'w') as f:
+        f.write('train  = LINEMOD/ape/train.txt\nvalid  = LINEMOD/ape/test.txt\nbackup = backup/ape\n'
+                'mesh = LINEMOD/ape/ape.ply\ntr_range = LINEMOD/ape/training_range.txt\nname = ape\ndiam = 0.103\n'
+                'gpus = 0\nnum_workers = 0\nwidth = 640\nheight = 480\nfx = %s\nfy = %s\nu0 = %s\nv0 = %s\n' % (FX, FY, U0, V0))
+    src = open(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).read().split('\n')
+    out = []
+    for line in src:
+        key = line.split('=')[0].strip()
+        if key == 'batch':
+            line = 'batch=%d' % batch
+        elif key == 'max_epochs':
+            line = 'max_epochs=%d' % max_epochs
+        out.append(line)
+    cfgfile = os.path.join(root, 'cfg', 'yolo-pose.cfg')
+    with open(cfgfile, 'w') as f:
+        f.write('\n'.join(out))
+    blocks = parse_cfg(cfgfile)
+    state = seeded_state(blocks, weights_seed)
+    # A head that predicts a plausible box (so that PnP is well posed on the predictions, as with trained weights):
+    # tiny image-dependent weights on the 18 coordinate channels (sub-pixel jitter: OpenCV-style DLT + LM lands in bad
+    # local minima from a few pixels of noise on a box this small) on top of a bias = centroid at the cell centre,
+    # corners at the offsets of a canonical pose (in cells of the 21 x 21 test grid); the confidence channel keeps
+    # full-size weights, so its arg-max cell is decided by margins far above the 1e-4 conv tolerance.
+    head = [e for e in state if e is not None][-1]
+    head['weight'][:18] *= 0.0002
+    head['weight'][18:] *= 0.1
+    Rc = _rodrigues(np.array([1.0, 1.0, 0.0]), 0.5)
+    pc, _ = _project(box, Rc, np.array([0.0, 0.0, 0.9]))
+    bias = np.zeros(20, dtype=np.float32)
+    for k in range(1, 9):
+        bias[2 * k] = 0.5 + (pc[k, 0] - pc[0, 0]) / W * 21          # corners are offsets from the cell's corner;
+        bias[2 * k + 1] = 0.5 + (pc[k, 1] - pc[0, 1]) / H * 21      # the centroid (sigmoid(0) = 0.5) sits at its centre
+    import torch
+    head['bias'] = torch.from_numpy(bias)
+    write_weights(os.path.join(root, 'init.weights'), blocks, state)
+    return dict(root=root, n_train=n_train, n_test=n_test, batch=batch)
+
+
+if __name__ == '__main__':
+    import sys
+    sys.path.insert(0, ROOT)
+    print(make(sys.argv[1]))
+
+
+# ---- parsing what the reference's drivers print (valid.py:205-222, region_loss.py:173) ----
+def parse_valid_output(text):
+    import re
+    out = {}
+    pats = {
+        'acc_2d_5px': r'Acc using 5 px 2D Projection = ([-\d.eE+]+)%',
+        'acc_3d_10pct': r'Acc using 10% threshold - ([-\d.eE+]+) vx 3D Transformation = ([-\d.eE+]+)%',
+        'acc_5cm5deg': r'Acc using 5 cm 5 degree metric = ([-\d.eE+]+)%',
+        'means': r'Mean 2D pixel error is ([-\d.eE+naninf]+), Mean vertex error is ([-\d.eE+naninf]+), mean corner error is ([-\d.eE+naninf]+)',
+        'errors': r'Translation error: ([-\d.eE+naninf]+) m, angle error: ([-\d.eE+naninf]+) degree, pixel error:\s+([-\d.eE+naninf]+) pix',
+        'nsamples': r'Number of test samples: (\d+)',
+    }
+    m = {k: re.search(p, text) for k, p in pats.items()}
+    missing = [k for k, v in m.items() if v is None]
+    if missing:
+        raise ValueError("valid.py output lacks %s:\n%s" % (missing, text[-2000:]))
+    out['acc_2d_5px'] = float(m['acc_2d_5px'].group(1))
+    out['adi_threshold'] = float(m['acc_3d_10pct'].group(1))          # 0.1 * calc_pts_diameter(mesh) (valid.py:72,200)
+    out['acc_3d_10pct'] = float(m['acc_3d_10pct'].group(2))
+    out['acc_5cm5deg'] = float(m['acc_5cm5deg'].group(1))
+    out['mean_pixel_err'], out['mean_vertex_err'], out['mean_corner_err'] = (float(v) for v in m['means'].groups())
+    out['trans_err'], out['angle_err'], out['pixel_err'] = (float(v) for v in m['errors'].groups())
+    out['nsamples'] = int(m['nsamples'].group(1))
+    return out
+
+
+def parse_train_output(text):
+    import re
+    rows = []
+    for m in re.finditer(r'^(\d+): nGT (\d+), recall (\d+), proposals (\d+), loss: x ([-\d.eE+]+), y ([-\d.eE+]+), '
+                         r'conf ([-\d.eE+]+), total ([-\d.eE+]+)$', text, re.M):
+        g = m.groups()
+        rows.append(dict(seen=int(g[0]), nGT=int(g[1]), recall=int(g[2]), proposals=int(g[3]), loss_x=float(g[4]),
+                         loss_y=float(g[5]), loss_conf=float(g[6]), total=float(g[7])))
+    lr = re.findall(r'epoch (\d+), processed (\d+) samples, lr ([-\d.eE+]+)', text)
+    return dict(steps=rows, epochs=[dict(epoch=int(a), processed=int(b), lr=float(c)) for a, b, c in lr])

@@ -399,3 +399,60 @@ def test_eval_caches_follow_weight_loading(tmp_path):
         bn_o.running_var.mul_(2.0)
         assert torch.equal(model(x), other(x))
         assert not torch.equal(model(x), y_b)
+
+
+def test_eval_train_eval_without_optimizer_step_refreshes_bn_constants():
+    """eval -> train-mode forward (no optimizer step in between: BN recalibration, gradient accumulation with a
+    periodic eval) -> eval on the same shape: the second eval must use the UPDATED running statistics, not the cached
+    constants of the first eval nor the training batch's scale/shift left in the shared vectors; a second plan (other
+    shape) must notice too."""
+    from oracle.darknet_ref import forward_ref
+    from oracle.step_check import snapshot_state
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 55)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 96, 96, generator=g)
+    x2 = torch.rand(1, 3, 128, 128, generator=g)
+    xt = torch.rand(2, 3, 96, 96, generator=g) * 3.0 + 1.0          # shifts the running statistics visibly
+    model.eval()
+    with torch.no_grad():
+        y0 = model(x.cuda()).clone()
+        z0 = model(x2.cuda()).clone()
+        model.train()
+        model(xt.cuda())
+        model.eval()
+        y1 = model(x.cuda()).clone()
+        z1 = model(x2.cuda()).clone()
+    assert not torch.equal(y0, y1) and not torch.equal(z0, z1)
+    st = snapshot_state(model)                                     # running statistics as they are now
+    with torch.no_grad():
+        ref_y = forward_ref(model.blocks, st, x, training=False)
+        ref_z = forward_ref(model.blocks, st, x2, training=False)
+    assert rel_err(y1.cpu().numpy(), ref_y.numpy()) < TOL
+    assert rel_err(z1.cpu().numpy(), ref_z.numpy()) < TOL
+
+
+def test_eval_forward_with_autograd_on_takes_the_inference_chain_and_can_still_backprop():
+    """valid.py:113 `Variable(data, volatile=True)` is a no-op on current torch: the unchanged callers run eval forwards
+    with grad mode on.  That must not allocate / repack the 202 MB data-gradient operands nor skip the fused inference
+    launches - and a backward through it (frozen-BN fine-tuning) must still be right."""
+    from oracle.darknet_ref import forward_ref
+    model, state = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 56)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 96, 96, generator=g)
+    probe = torch.randn(2, 20, 3, 3, generator=g)
+    model.eval()
+    with torch.no_grad():
+        y_ng = model(x.cuda()).clone()
+    y = model(x.cuda())                       # grad mode on, eval mode
+    plan = list(model._plans.values())[0]
+    assert y.requires_grad and torch.equal(y.detach(), y_ng)
+    assert plan._dpack is None and plan.dgrad_ready is None      # no data-gradient operands were built
+    (y * probe.cuda()).sum().backward()
+    st = clone_state(state, requires_grad=True)
+    ref = forward_ref(model.blocks, st, x, training=False)
+    (ref * probe).sum().backward()
+    for ind, e in enumerate(st):
+        if e is not None:
+            assert rel_err(model.models[ind][0].weight.grad.cpu().numpy(), e['weight'].grad.numpy()) < 3e-4, ind
+            if 'bn_weight' in e:
+                assert rel_err(model.models[ind][1].weight.grad.cpu().numpy(), e['bn_weight'].grad.numpy()) < 3e-4, ind

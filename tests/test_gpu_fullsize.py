@@ -1,0 +1,124 @@
+"""The configurations the headline numbers are quoted on, end to end, with the autotuned plans active.
+
+BASELINE.json config 2 (cfg/yolo-pose.cfg, B = 64, 416 x 416, train step) and config 5 (cfg/yolo-pose-multi.cfg, full
+trunk, 1-8 labels per image) against the CPU oracle through oracle/step_check.py: head output, RegionLoss, BatchNorm
+running statistics <= 1e-4 against an independent oracle forward; every conv launch's raw output <= 1e-4 against the
+oracle's convolution of the same inputs; whole-network parameter gradients against the DECISION-FROZEN oracle
+backward (strict bar: no fp32-vs-fp64 envelope).  Reference: /root/reference/train.py:76-106, region_loss.py:95-175,
+multi_obj_pose_estimation/train_multi.py:60-100, region_loss_multi.py:94-189.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLD, ROOT, load_state_into, make_targets
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GRAD_TOL = 3e-4      # whole-network gradients, decision-frozen (same bar the 96x96 nets meet against a free-running oracle)
+
+
+def _report(tag, res):
+    from oracle.step_check import summarize
+    worst = sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:3]
+    print('%s: %s | worst grads %s | plans %s' % (tag, summarize(res), worst,
+                                                   [(i, f, d) for i, f, d in res['plans'] if f or d]))
+
+
+def _assert_step(res):
+    assert res['head'] < TOL, res['head']
+    assert res['loss'] < TOL, (res['loss_gpu'], res['loss_ref'])
+    assert res['running'] < TOL, res['running']
+    assert res['conv'] < TOL, res['conv_by_layer']
+    assert res['grad_out'] < TOL, res['grad_out']
+    assert res['grad'] < GRAD_TOL, sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_headline_config_b64_train_step_with_tuned_plans():
+    """Exactly what bench.py times: torch.manual_seed(0) default-initialised cfg/yolo-pose.cfg, batch 64 of synthetic
+    416 x 416 images with one label each (bench.synthetic_batch, seed 1000), epoch 20, autotuner on."""
+    sys.path.insert(0, ROOT)
+    from bench import synthetic_batch
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    assert os.environ.get('SSP_AUTOTUNE', '1') != '0'
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).cuda()
+    x, tgt = synthetic_batch(64, 416, 416, 1000, 'cpu')
+    n_rej = len(engine.TUNE_REJECTED)
+    res = check_train_step(model, RegionLoss(), x, tgt, 20)
+    _report('yolo-pose B=64 416', res)
+    assert any(f or d for _, f, d in res['plans']), "the autotuner picked no plan: nothing tuned was exercised"
+    assert len(engine.TUNE_REJECTED) == n_rej, engine.TUNE_REJECTED[n_rej:]
+    _assert_step(res)
+
+
+def test_headline_config_b8_seeded_weights_pretrain_epoch():
+    """The cfg's own batch (batch=8, yolo-pose.cfg:3) with seeded non-trivial BN parameters / running statistics, epoch 0
+    (<= pretrain: no confidence term, region_loss.py:157-161) and 1-3 labels per image."""
+    from oracle.darknet_ref import seeded_state
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 11))
+    model = model.cuda()
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.uniform(0, 1, (8, 3, 416, 416)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, 8, [1, 2, 1, 3, 1, 1, 2, 1]))
+    res = check_train_step(model, RegionLoss(), x, tgt, 0)
+    _report('yolo-pose B=8 416 epoch 0', res)
+    _assert_step(res)
+
+
+def test_multi_object_full_trunk_train_step():
+    """BASELINE config 5: cfg/yolo-pose-multi.cfg (full Darknet-19 trunk, head 5 anchors x 32 = 160 channels), B = 8,
+    1-8 labels per image with OCCLUSION-style class ids, region_loss_multi with the cfg's anchors."""
+    from oracle.darknet_ref import seeded_state
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd.darknet import DarknetMulti
+    from singleshotpose_amd.region_loss import RegionLossMulti
+    model = DarknetMulti(os.path.join(ROOT, 'cfg', 'yolo-pose-multi.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 19))
+    model = model.cuda()
+    rs = np.random.RandomState(9)
+    B = 8
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, 416, 416)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [1, 2, 3, 4, 5, 6, 7, 8], multi=True))
+    crit = RegionLossMulti(num_keypoints=9, num_classes=13, anchors=model.anchors, num_anchors=5, pretrain_num_epochs=0)
+    kw = dict(num_classes=13, num_anchors=5, anchors=model.anchors, pretrain_num_epochs=0, multi=True)
+    res = check_train_step(model, crit, x, tgt, 1, loss_kwargs=kw)
+    _report('yolo-pose-multi B=8 416', res)
+    assert tuple(model._plans.keys())[0][:3] == (B, 416, 416)
+    _assert_step(res)
+
+
+def test_tuned_plans_every_candidate_matches_default_on_bench_shapes():
+    """Every plan code the autotuner may hand to a launch (engine.Plan._autotune candidates), on two of the benchmark's
+    launch shapes (64 x 13 x 13, 1024 -> 1024 and 64 x 26 x 26, 256 -> 512): identical results to the default plan
+    up to fp32 summation order."""
+    from gpu_util import dev, stream
+    from singleshotpose_amd import _lib
+    cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for (B, H, W, Cin, Cout, R) in ((64, 13, 13, 1024, 1024, 3), (64, 26, 26, 256, 512, 3)):
+        M = B * H * W
+        x = torch.empty(M * Cin, device=dev()).uniform_(-1, 1, generator=g)
+        w = torch.empty(Cout * R * R * Cin, device=dev()).uniform_(-0.05, 0.05, generator=g)
+        outs = {}
+        for code in (0,) + cands:
+            wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, code))
+            ws = torch.empty(wsn, device=dev())
+            out = torch.zeros(M * Cout, device=dev())
+            _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout, Cin,
+                      Cout, R, 0, code, ws.data_ptr(), wsn, stream())
+            outs[code] = out
+        torch.cuda.synchronize()
+        den = float(outs[0].abs().max())
+        for code in cands:
+            assert float((outs[code] - outs[0]).abs().max()) <= 1e-5 * den, (code, B, H, W, Cin, Cout)

@@ -389,3 +389,47 @@ def test_conv_hybrid_launch_matches_plain(plan):
     ref = F.conv2d(x[-2:], w, None, padding=1)
     got = G.from_nhwc(torch.from_numpy(o_hyb[-2 * H * W:]), 2, Cout, H, W)
     assert rel_err(got.numpy(), ref.numpy()) < TOL
+
+
+def test_conv_plan_is_an_argument_two_threads_two_plans():
+    """the boundary is re-entrant - the tile / split plan travels with the call, so two host
+    threads running different plans on different streams (two models, two shapes) get bit-identical results to the
+    same launches issued serially.  (Round 1 set a process-global knob before every launch.)"""
+    import threading
+    G, _lib = _imports()
+    B, H, W, Cin, Cout, R = 8, 13, 13, 512, 1024, 3
+    M = B * H * W
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.empty(M * Cin, device=G.dev()).uniform_(-1, 1, generator=g)
+    w = torch.empty(Cout * R * R * Cin, device=G.dev()).uniform_(-0.05, 0.05, generator=g)
+    plans = (12834, 6464)           # split-K x3 on 128-row tiles / split-K x6 on 64-row tiles
+
+    def run(code, stream, out, ws, wsn, reps):
+        for _ in range(reps):
+            _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout, Cin,
+                      Cout, R, 0, code, ws.data_ptr(), wsn, stream.cuda_stream)
+
+    def buffers(code):
+        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, code))
+        assert wsn >= (code // 10 % 10) * M * Cout
+        return torch.zeros(M * Cout, device=G.dev()), torch.empty(wsn, device=G.dev()), wsn
+
+    serial = []
+    for code in plans:
+        out, ws, wsn = buffers(code)
+        run(code, torch.cuda.current_stream(), out, ws, wsn, 1)
+        torch.cuda.synchronize()
+        serial.append(out.clone())
+    assert not torch.equal(serial[0], serial[1])            # different summation orders: the plans really differ
+    assert rel_err(serial[1].cpu().numpy(), serial[0].cpu().numpy()) < 1e-5
+    streams = [torch.cuda.Stream() for _ in plans]
+    bufs = [buffers(code) for code in plans]
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=run, args=(code, s, b[0], b[1], b[2], 200)) for code, s, b in zip(plans, streams, bufs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for got, want in zip(bufs, serial):
+        assert torch.equal(got[0], want)

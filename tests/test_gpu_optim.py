@@ -160,3 +160,51 @@ def test_cpu_parameters_raise():
     p.grad = torch.ones(8)
     with pytest.raises(RuntimeError, match="HIP kernel only"):
         SGD([p], lr=0.1).step()
+
+
+def test_fused_optimizer_honours_momentum_restored_by_load_state_dict():
+    """Resume: a fresh optimizer that load_state_dict()s saved momentum must continue from it (torch.optim.SGD does),
+    both when the state is loaded BEFORE the first fused step (the flat layout adopts the loaded buffers and the step
+    is not a 'first' step) and when it is loaded AFTER adoption (the momentum tensors are swapped under the flat
+    buffer: the layout is re-adopted)."""
+    from singleshotpose_amd.optim import SGD
+    from singleshotpose_amd.region_loss import RegionLoss
+    kw = dict(lr=1e-3 / 4, momentum=0.9, dampening=0, weight_decay=0.0005 * 4)
+    crit = RegionLoss()
+    crit.verbose = False
+
+    def one_step(model, opt, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(4, 3, 96, 96, generator=g).cuda()
+        tgt = torch.from_numpy(make_targets(np.random.RandomState(seed), 4, [1] * 4))
+        opt.zero_grad()
+        crit(model(x), tgt, 20).backward()
+
+    a = _tiny().cuda().train()
+    oa = SGD(a.parameters(), **kw)
+    for s in (1, 2):
+        one_step(a, oa, s)
+        oa.step()
+    saved_model = {k: v.clone() for k, v in a.state_dict().items()}
+    saved_opt = oa.state_dict()
+    saved_mom = [oa.state[p]['momentum_buffer'].clone() for p in a.parameters()]
+
+    for when in ('before_first_step', 'after_adoption'):
+        b = _tiny().cuda().train()
+        b.load_state_dict(saved_model)
+        ob = SGD(b.parameters(), **kw)
+        if when == 'after_adoption':
+            one_step(b, ob, 7)
+            ob.step()                               # adopts the flat layout with its own momentum
+            b.load_state_dict(saved_model)
+        ob.load_state_dict(saved_opt)
+        sh, osh = _shadow(b, lambda ps: torch.optim.SGD(ps, **kw))
+        for q, m in zip(sh, saved_mom):
+            osh.state[q]['momentum_buffer'] = m.detach().cpu().clone()
+        one_step(b, ob, 3)
+        _shadow_step(b, sh, osh)
+        ob.step()
+        assert ob.fused_steps >= 1
+        for (n, p), q in zip(b.named_parameters(), sh):
+            assert rel_err(p.detach().cpu().numpy(), q.detach().numpy()) < 1e-6, (when, n)
+            assert rel_err(ob.state[p]['momentum_buffer'].cpu().numpy(), osh.state[q]['momentum_buffer'].numpy()) < 1e-6, (when, n)

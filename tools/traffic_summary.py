@@ -21,5 +21,8 @@ for k, d in agg.items():
         'fetch_bytes_per_launch_corrected': 2.0 * 1024.0 * sum(fetch) / max(len(fetch), 1),
         'write_bytes_per_launch_reported': 1024.0 * sum(write) / max(len(write), 1),
     }
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from singleshotpose_amd._lib import csrc_digest
+res['_meta'] = {'csrc_sha1': csrc_digest(), 'note': 'digest of singleshotpose_amd/csrc + include/ssp_hip.h at profile time'}
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in list(res.items())[:40]}, indent=1)[:3000])
