@@ -7,14 +7,14 @@ export TMPDIR=/tmp
 # kernel statistics contain the training step's launches only (no autotune trial launches)
 export SSP_TUNE_CACHE=$(pwd)/gpurun_out/tune_cache_$TAG.json
 rm -f $SSP_TUNE_CACHE
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/pytest_$TAG.log
+timeout 2400 python -m pytest tests -m gpu -q -rfP -p no:cacheprovider --durations=15 > gpurun_out/pytest_$TAG.log 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
-timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 cat gpurun_out/bench_$TAG.json
 REPO=$(pwd)
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_$TAG.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-extras > $REPO/gpurun_out/prof_$TAG.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_traffic_$TAG/$C -o p -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_traffic_$TAG/$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_traffic_$TAG/$C -o p -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-extras > $REPO/gpurun_out/pmc_traffic_$TAG/$C.log 2>&1
 done
 cd $REPO
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
@@ -23,4 +23,4 @@ find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +8M -delete
 find gpurun_out/pmc_traffic_$TAG -name "*kernel_trace.csv" -delete
 python tools/traffic_summary.py gpurun_out/pmc_traffic_$TAG gpurun_out/traffic_$TAG.json | head -60
 tail -3 gpurun_out/smoke_$TAG.log
-tail -4 gpurun_out/pytest_$TAG.log
+grep -E "^(FAILED|ERROR)|passed|failed|yolo-pose|error" gpurun_out/pytest_$TAG.log | tail -40
