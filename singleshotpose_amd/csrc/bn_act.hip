@@ -193,7 +193,11 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
   const bool active = (pp < ppb) && (g4 < G);
   const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  // fp64 accumulators: the two sums cancel heavily (dy has mixed signs) and feed mean(dy) / mean(dy*xhat), which the
+  // apply pass subtracts from EVERY pixel - an error there is coherent, and a following filter gradient against a
+  // non-centred input (the image itself for the first layer) amplifies it by sqrt(#pixels): with fp32 per-thread sums
+  // the first layer's dW sat 1.6e-3 from the reference at B = 64 (PyTorch's CPU batch_norm_backward sums in double too)
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   if (active) {
     const int c = g4 * 4;
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
@@ -210,33 +214,35 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
       BwdItem it = bwd_item(x, ldx, g, ldg, po, p00, W, c, pool, slope, sc, sh, mu, is);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        s1[k] += it.dyv[k];
-        s2[k] += it.dyv[k] * it.xh[k];
+        s1[k] += (double)it.dyv[k];
+        s2[k] += (double)it.dyv[k] * (double)it.xh[k];
       }
     }
   }
-  __shared__ f32x4 r1[256], r2[256];
-  r1[tid] = s1; r2[tid] = s2;
+  __shared__ double r1[256][4], r2[256][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { r1[tid][k] = s1[k]; r2[tid][k] = s2[k]; }
   __syncthreads();
   if (tid < gpb && g4 < G) {
-    f32x4 a = r1[tid], b = r2[tid];
-    for (int q = 1; q < ppb; ++q) {
-      f32x4 u = r1[tid + q * gpb], v = r2[tid + q * gpb];
+    double a[4], b[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a[k] += u[k]; b[k] += v[k]; }
+    for (int k = 0; k < 4; ++k) { a[k] = r1[tid][k]; b[k] = r2[tid][k]; }
+    for (int q = 1; q < ppb; ++q) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[k] += r1[tid + q * gpb][k]; b[k] += r2[tid + q * gpb][k]; }
     }
     if (acc_dbeta != nullptr) {
       // single-pass mode: the (<= 1024) workgroup sums go straight into the zero-initialised gradients with fp32
       // hardware atomics; no finalize launch sits between this kernel and the apply pass
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        atomicAdd(acc_dbeta + g4 * 4 + k, a[k]);
-        atomicAdd(acc_dgamma + g4 * 4 + k, b[k]);
+        atomicAdd(acc_dbeta + g4 * 4 + k, (float)a[k]);
+        atomicAdd(acc_dgamma + g4 * 4 + k, (float)b[k]);
       }
     } else {
       float* dst = partial + ((int64_t)blockIdx.x * C + g4 * 4) * 2;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { dst[2 * k] = a[k]; dst[2 * k + 1] = b[k]; }
+      for (int k = 0; k < 4; ++k) { dst[2 * k] = (float)a[k]; dst[2 * k + 1] = (float)b[k]; }
     }
   }
 }
@@ -416,6 +422,25 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(total)), dim3(256), 0, stream, x, ldx, g, ldg, dx, lddx,
                        scale, shift, mean, invstd, c1, c2, 1.f, C, B, H, W, pool, slope);
   }
+  SSP_CHECK_LAUNCH("bn_act_bwd_apply");
+  return SSP_OK;
+}
+
+// The two reductions were already done by the producing data-gradient launch (ssp_conv_dgrad_bnbwd: one (sum dy,
+// sum dy * xhat) pair per M tile and channel): fp64 finalize over the tiles, then the apply pass.  Un-pooled blocks only.
+int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   int C, int B, int H, int W, float slope, int training, const float* partial,
+                                   int npartial, float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream) {
+  SSP_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && lddx % 4 == 0, "bn_act_bwd_partials: C and strides must be multiples of 4");
+  SSP_CHECK_ARG(partial != nullptr && npartial > 0, "bn_act_bwd_partials: no partial sums");
+  const int64_t npix = (int64_t)B * H * W;
+  SspProfScope prof(SSP_PROF_BN_ACT, stream, 4.0 * C * 3.0 * (double)npix);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, npartial, C,
+                     1.0 / (double)npix, training, dgamma, dbeta, c1, c2);
+  SSP_CHECK_LAUNCH("bn_bwd_finalize");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(npix * (C / 4))), dim3(256), 0, stream, x, ldx, g, ldg, dx,
+                     lddx, scale, shift, mean, invstd, c1, c2, 1.f, C, B, H, W, 0, slope);
   SSP_CHECK_LAUNCH("bn_act_bwd_apply");
   return SSP_OK;
 }

@@ -291,7 +291,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias, float* stats, int M,
                                                             int Cout, int tile_m, int accumulate,
                                                             const float* __restrict__ escale, float act_slope,
-                                                            int row0) {
+                                                            int row0, const float* __restrict__ bn_raw, int bn_ld,
+                                                            const float* __restrict__ bn_scale,
+                                                            const float* __restrict__ bn_shift,
+                                                            const float* __restrict__ bn_mean,
+                                                            const float* __restrict__ bn_invstd, float bn_slope,
+                                                            float* bn_partial) {
   // rows [row0, M) (row0 a multiple of tile_m); workspace row m sits at m - row0, split stride (M - row0) rows
   const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
   const int c = blockIdx.y * 64 + gl * 4;
@@ -305,6 +310,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   if (cok && bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(bias + c);
   f32x4 e4 = {1.f, 1.f, 1.f, 1.f};
   if (cok && escale != nullptr) e4 = *reinterpret_cast<const f32x4*>(escale + c);
+  // fused BatchNorm-backward reductions of the block that produced this gradient's activation (ConvArgs::bn_*)
+  const bool bnb = bn_partial != nullptr;
+  f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc, s1 = bsc, s2 = bsc;
+  if (bnb && cok) {
+    bsc = *reinterpret_cast<const f32x4*>(bn_scale + c); bsh = *reinterpret_cast<const f32x4*>(bn_shift + c);
+    bmu = *reinterpret_cast<const f32x4*>(bn_mean + c); bis = *reinterpret_cast<const f32x4*>(bn_invstd + c);
+  }
   if (cok) {
     for (int m = m0 + pp; m < m1; m += 16) {
       f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
@@ -329,10 +341,37 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         o[0] += prev[0]; o[1] += prev[1]; o[2] += prev[2]; o[3] += prev[3];
       }
       *reinterpret_cast<f32x4*>(dst) = o;
+      if (bnb) {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(bn_raw + (int64_t)m * bn_ld + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float y = xr[k] * bsc[k] + bsh[k];
+          const float dyv = y > 0.f ? o[k] : o[k] * bn_slope;
+          s1[k] += dyv;
+          s2[k] += dyv * ((xr[k] - bmu[k]) * bis[k]);
+        }
+      }
     }
   }
+  __shared__ float red[16][16][9];   // [row lane][channel quad][cnt, mean x4, m2 x4]  (or [-, s1 x4, s2 x4])
+  if (bnb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[pp][gl][1 + k] = s1[k]; red[pp][gl][5 + k] = s2[k]; }
+    __syncthreads();
+    if (tid < 64) {
+      const int q = tid >> 2, k = tid & 3;
+      const int ch = blockIdx.y * 64 + tid;
+      if (ch < Cout) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 16; ++w) { a += red[w][q][1 + k]; b += red[w][q][5 + k]; }
+        float* dst = bn_partial + ((int64_t)(m0 / tile_m) * Cout + ch) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
+    return;
+  }
   if (stats == nullptr) return;
-  __shared__ float red[16][16][9];   // [row lane][channel quad][cnt, mean x4, m2 x4]
   red[pp][gl][0] = cnt;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { red[pp][gl][1 + k] = mean[k]; red[pp][gl][5 + k] = m2[k]; }
@@ -432,7 +471,7 @@ int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan) {
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
                           int64_t ws_floats, int plan, int prof_kind, hipStream_t stream, const float* escale,
-                          float act_slope) {
+                          float act_slope, const SspBnBwdFuse* bnb) {
   SSP_CHECK_ARG(R == 1 || R == 3, "conv: only 1x1 and 3x3 filters are supported (got %d)", R);
   SSP_CHECK_ARG(Cin % 4 == 0 && Cin > 0, "conv: Cin must be a positive multiple of 4 (got %d)", Cin);
   SSP_CHECK_ARG(ldin % 4 == 0 && ldin >= Cin, "conv: ldin must be a multiple of 4 and >= Cin");
@@ -446,6 +485,19 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   a.probe = 0;
   a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;
+  a.bn_raw = nullptr; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr; a.bn_partial = nullptr;
+  a.bn_ld = 0; a.bn_slope = 1.f;
+  if (bnb != nullptr && bnb->partial != nullptr) {
+    SSP_CHECK_ARG(accumulate == 0 && bias == nullptr && stats == nullptr && escale == nullptr,
+                  "conv: the fused BatchNorm-backward reductions need a plain (non-accumulating) data-gradient launch");
+    SSP_CHECK_ARG(bnb->raw != nullptr && bnb->scale != nullptr && bnb->shift != nullptr && bnb->mean != nullptr &&
+                  bnb->invstd != nullptr && bnb->ldraw >= Cout && Cout % 4 == 0 && bnb->ldraw % 4 == 0 &&
+                  ((((uintptr_t)bnb->raw) | ((uintptr_t)bnb->scale) | ((uintptr_t)bnb->shift) | ((uintptr_t)bnb->mean) |
+                    ((uintptr_t)bnb->invstd)) & 15) == 0,
+                  "conv: bad BatchNorm-backward operands (16-byte aligned, Cout %% 4 == 0, ldraw >= Cout)");
+    a.bn_raw = bnb->raw; a.bn_ld = bnb->ldraw; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift; a.bn_mean = bnb->mean;
+    a.bn_invstd = bnb->invstd; a.bn_slope = bnb->slope; a.bn_partial = bnb->partial;
+  }
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
   a.ksplit = pl.ksplit;
   a.ws = ws;
@@ -508,11 +560,13 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   if (rc != SSP_OK) return rc;
   if (pl.ksplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
-                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, 0);
+                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, 0, a.bn_raw, a.bn_ld, a.bn_scale,
+                       a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial);
     SSP_CHECK_LAUNCH("splitk_reduce");
   } else if (a.tail_ks > 1) {     // hybrid launch: only the tail rows were left as partials
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
-                       a.tail_ks, out, ldout, bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, a.ws_row0);
+                       a.tail_ks, out, ldout, bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, a.ws_row0,
+                       a.bn_raw, a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial);
     SSP_CHECK_LAUNCH("splitk_reduce(tail)");
   }
   return SSP_OK;

@@ -25,6 +25,19 @@ struct ConvArgs {
   int ws_row0, ws_rows;
   int col_major;       // tile order inside a launch: tile_m fastest (workgroups resident on one XCD share a filter slab)
   int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
+  // Data-gradient launches only: BatchNorm-backward reductions of the block that PRODUCED the activation whose gradient
+  // this launch writes (out = g = dL/d leaky(BN(raw))).  With bn_partial set, the finishing pass (tile epilogue or
+  // splitk_reduce_kernel) also reads that block's raw conv output at the tile's positions and leaves, per M tile and
+  // channel, (sum dy, sum dy * xhat) with dy = g * leaky'(scale*raw+shift), xhat = (raw-mean)*invstd - what
+  // bn_act_bwd_reduce_kernel would otherwise re-read both g and raw for (darknet.py:157,162 autograd).
+  const float* bn_raw;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  float* bn_partial;   // [ntile_m][Cout][2] or nullptr
+  int bn_ld;
+  float bn_slope;
 };
 
 __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
@@ -64,8 +77,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
     }
     return;
   }
-  auto body = [&](auto accum_tag) {
+  auto body = [&](auto accum_tag, auto bnb_tag) {
     constexpr bool ACCUM = decltype(accum_tag)::value;
+    constexpr bool BNB = decltype(bnb_tag)::value;     // fused BatchNorm-backward reductions (data-gradient launches)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WTN + j * 32 + li;
@@ -73,8 +87,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
       const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
       const float esc = (p.escale != nullptr && n_ok) ? p.escale[n] : 1.f;
       float cnt = 0.f, sum = 0.f;
+      float b_sc = 0.f, b_sh = 0.f, b_mu = 0.f, b_is = 0.f, s1 = 0.f, s2 = 0.f;
+      if constexpr (BNB) {
+        if (n_ok) { b_sc = p.bn_scale[n]; b_sh = p.bn_shift[n]; b_mu = p.bn_mean[n]; b_is = p.bn_invstd[n]; }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        float xr[16];
+        if constexpr (BNB) {
+          // the producing block's raw conv output at this lane's 16 rows: issued together, ahead of the stores
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            xr[r] = (m < p.M && n_ok) ? p.bn_raw[(int64_t)m * p.bn_ld + n] : 0.f;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -87,7 +114,22 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
             *o = v;
             cnt += 1.f;
             sum += acc[i][j][r];
+            if constexpr (BNB) {
+              const float y = xr[r] * b_sc + b_sh;
+              const float dyv = y > 0.f ? v : v * p.bn_slope;
+              s1 += dyv;
+              s2 += dyv * ((xr[r] - b_mu) * b_is);
+            }
           }
+        }
+      }
+      if constexpr (BNB) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const int col = wn * WTN + j * 32 + li;
+        if (lh == 0) {
+          smem[(wm * BN + col) * 2 + 0] = s1;
+          smem[(wm * BN + col) * 2 + 1] = s2;
         }
       }
       if (p.stats != nullptr) {
@@ -118,7 +160,23 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
       }
     }
   };
-  if (p.accumulate) body(std::true_type{}); else body(std::false_type{});
+  if (p.bn_partial != nullptr) body(std::false_type{}, std::true_type{});       // never with accumulate (checked on the host)
+  else if (p.accumulate) body(std::true_type{}, std::false_type{});
+  else body(std::false_type{}, std::false_type{});
+  if (p.bn_partial != nullptr) {
+    __syncthreads();
+    for (int col = tid; col < BN; col += NT) {
+      const int n = n0 + col;
+      if (n < p.Cout) {
+        float a = smem[col * 2 + 0], b = smem[col * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) { a += smem[(w * BN + col) * 2 + 0]; b += smem[(w * BN + col) * 2 + 1]; }
+        float* dst = p.bn_partial + ((int64_t)tile_m * p.Cout + n) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
+  }
   if (p.stats != nullptr) {
     __syncthreads();
     for (int col = tid; col < BN; col += NT) {

@@ -13,7 +13,7 @@ int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan);
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
                           int64_t ws_floats, int plan, int prof_kind, hipStream_t stream,
-                          const float* escale = nullptr, float act_slope = 1.f);
+                          const float* escale = nullptr, float act_slope = 1.f, const SspBnBwdFuse* bnb = nullptr);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
@@ -28,6 +28,10 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
                           const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
                           int pool, float slope, int training, float* partial, float* dgamma, float* dbeta, float* c1,
                           float* c2, hipStream_t stream);
+int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   int C, int B, int H, int W, float slope, int training, const float* partial,
+                                   int npartial, float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream);
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
 int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float dampening,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
@@ -173,6 +177,26 @@ int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, in
                    void* stream) {
   return ssp_conv_igemm_launch(dy, wt, dx, nullptr, nullptr, B, H, W, Cout_dy, Cin_dx, lddy, lddx, R, accumulate,
                                workspace, workspace_floats, plan, SSP_PROF_CONV_DGRAD, (hipStream_t)stream);
+}
+
+int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx,
+                         int lddy, int lddx, int R, int plan, float* workspace, int64_t workspace_floats,
+                         const float* raw, int ldraw, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, float slope, float* partial, void* stream) {
+  SspBnBwdFuse f = {raw, ldraw, scale, shift, mean, invstd, slope, partial};
+  if (partial == nullptr) {
+    ssp_set_error("conv_dgrad_bnbwd: partial must not be NULL (use ssp_conv_dgrad)");
+    return SSP_ERR_ARG;
+  }
+  return ssp_conv_igemm_launch(dy, wt, dx, nullptr, nullptr, B, H, W, Cout_dy, Cin_dx, lddy, lddx, R, 0, workspace,
+                               workspace_floats, plan, SSP_PROF_CONV_DGRAD, (hipStream_t)stream, nullptr, 1.f, &f);
+}
+int ssp_bn_act_bwd_partials(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
+                            float slope, int training, const float* partial, int npartial, float* dgamma, float* dbeta,
+                            float* c1, float* c2, void* stream) {
+  return ssp_bn_act_bwd_partials_launch(x, ldx, g, ldg, dx, lddx, scale, shift, mean, invstd, C, B, H, W, slope, training,
+                                        partial, npartial, dgamma, dbeta, c1, c2, (hipStream_t)stream);
 }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,

@@ -68,6 +68,18 @@ struct SspKernelCache {
 // Returns SSP_OK and the resident-workgroup count in *slots (may be nullptr); configures the kernel on first use.
 int ssp_kernel_prepare(const void* kern, int lds_bytes, int threads, SspKernelCache* cache, int* slots, const char* name);
 
+// BatchNorm-backward reductions fused into a data-gradient launch (ConvArgs::bn_*, include/ssp_hip.h ssp_conv_dgrad_bnbwd)
+struct SspBnBwdFuse {
+  const float* raw;      // raw conv output of the block that produced dx's activation, [pixels][ldraw]
+  int ldraw;
+  const float* scale;    // that block's forward BN vectors (ssp_bn_fwd_finalize / ssp_bn_eval_prepare)
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  float slope;
+  float* partial;        // out: [ceil(M / tile_m)][C][2] = (sum dy, sum dy * xhat) per M tile
+};
+
 static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Observed dispatch places workgroup b on XCD b%8 (MI355X_MICROARCH.md, "Workgroup dispatch").

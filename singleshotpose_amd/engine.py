@@ -305,11 +305,45 @@ class Plan(object):
                 cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
                                                             cs.cin, cs.k, cs.plan_dgrad)
                 need = max(need, cs.ws_dgrad)
+            self._plan_bn_fusion()
             if need > self.ws_floats:
                 torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
                 self.ws_floats = need
                 self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
                 self._graph = None          # a captured inference chain holds the old workspace pointer
+
+    def _plan_bn_fusion(self):
+        """BatchNorm-backward reductions folded into the producing data-gradient launch (ssp_conv_dgrad_bnbwd).
+
+        Block `src` qualifies when its (un-pooled) BN + leaky output feeds exactly one consumer and that consumer is a
+        conv: the consumer's dgrad writes g = dL/d out(src) - the tile it just finished holds g, one extra read of
+        src's raw conv output at the same positions gives sum(dy) and sum(dy * xhat) per tile, and the separate reduce
+        pass over raw + g (bn_act_bwd_reduce_kernel: a third of the step's BatchNorm-backward traffic, on the critical
+        stream) disappears.  Pooled blocks, blocks with two consumers (route sources) and blocks consumed through a
+        route / reorg keep the two-pass form.  SSP_BN_FUSE=0 turns it off (A/B)."""
+        on = os.environ.get('SSP_BN_FUSE', '1') != '0'
+        for cs in self.convs.values():
+            cs.bn_fuse_src = None
+            cs.bnp = None
+        if not on:
+            return
+        for cs in self.convs.values():
+            if cs.first:
+                continue
+            src = None
+            for i, a in enumerate(self.acts):
+                if a is cs.inp:
+                    src = i
+                    break
+            scs = self.convs.get(src)
+            if (scs is None or scs.pool or not scs.bn or not scs.needs_act or scs.out is not cs.inp or
+                    self.consumers[src] != [cs.ind] or scs.coutp != scs.cout or cs.cin != scs.cout or
+                    cs.inp.ld != scs.ldraw or cs.inp.off != 0 or cs.cin % 4):
+                continue
+            tm = _lib.query('ssp_conv_stats_tile_m', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.plan_dgrad)
+            ntile = (cs.M + tm - 1) // tm
+            cs.bn_fuse_src = scs
+            scs.bnp = (torch.empty(ntile * scs.cout * 2, dtype=torch.float32, device=self.device), ntile)
 
     def _repack_dgrad(self, cs, stream):
         src = cs.conv.weight.detach()
@@ -639,6 +673,7 @@ class Plan(object):
         blocks = self.net.blocks
         o = self.out_act
         written = set()
+        fused_stats = set()      # blocks whose BatchNorm-backward reductions were produced by their consumer's dgrad launch
         g_last = self._grad_buf(self.last, o)
         call('ssp_nchw_to_nhwc', grad_out.data_ptr(), g_last.ptr, B, o.C, o.H, o.W, o.C, o.ld, st)
         if o.ld > o.C:
@@ -708,10 +743,18 @@ class Plan(object):
                     else:
                         dg_ptr, db_ptr = v[6].data_ptr(), v[7].data_ptr()
                         partial = self.bn_partial.data_ptr()
-                    call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
-                         v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
-                         1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, partial,
-                         dg_ptr, db_ptr, v[4].data_ptr(), v[5].data_ptr(), st)
+                    if cs.ind in fused_stats:
+                        # the two reductions came out of the consumer's data-gradient launch: finalize + apply only
+                        ptile, ntile = cs.bnp
+                        call('ssp_bn_act_bwd_partials', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(),
+                             cs.ldraw, v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B,
+                             cs.H, cs.W, cs.slope, 1 if training else 0, ptile.data_ptr(), ntile, dg_ptr, db_ptr,
+                             v[4].data_ptr(), v[5].data_ptr(), st)
+                    else:
+                        call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
+                             v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
+                             1 if cs.pool else 0, cs.slope, 1 if (training and cs.bn) else 0, partial,
+                             dg_ptr, db_ptr, v[4].data_ptr(), v[5].data_ptr(), st)
                     dy_ptr, dy_ld = cs.raw.data_ptr(), cs.ldraw
                     if cs.bn and cs.coutp != cs.cout:
                         gview(cs.bnm.weight).copy_(v[6][:cs.cout])
@@ -739,9 +782,18 @@ class Plan(object):
                 if not cs.first:
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
-                    call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
-                         cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
-                         self.ws_floats, st)
+                    scs = getattr(cs, 'bn_fuse_src', None)
+                    if scs is not None and src not in written:
+                        sv = scs.vec
+                        call('ssp_conv_dgrad_bnbwd', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W,
+                             cs.coutp, cs.cin, dy_ld, gin.ld, cs.k, cs.plan_dgrad, self.ws.data_ptr(), self.ws_floats,
+                             scs.raw.data_ptr(), scs.ldraw, sv[2].data_ptr(), sv[3].data_ptr(), sv[0].data_ptr(),
+                             sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), st)
+                        fused_stats.add(src)
+                    else:
+                        call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
+                             cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
+                             self.ws_floats, st)
                     written.add(src)
             elif t == 'maxpool':
                 if ind not in written:

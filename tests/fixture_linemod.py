@@ -113,8 +113,9 @@ def make(root, n_train=16, n_test=8, batch=8, max_epochs=1, seed=0, weights_seed
         f.write('\n'.join(names[:n_train]) + '\n')
     with open(os.path.join(d, 'test.txt'), 'w') as f:
         f.write('\n'.join(names[n_train:]) + '\n')
-    for i in range(4):
-        Image.fromarray(_texture(rs, 375, 500)).save(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages', 'bg%d.png' % i))
+    # ONE background: train.py:308 lists this directory with os.listdir (utils.py:24-29), whose order is file-system
+    # dependent - with a single file the background drawn by dataset.py:100-101 is the same on every machine
+    Image.fromarray(_texture(rs, 375, 500)).save(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages', 'bg0.png'))
     with open(os.path.join(root, 'cfg', 'ape.data'), 'w') as f:
         f.write('train  = LINEMOD/ape/train.txt\nvalid  = LINEMOD/ape/test.txt\nbackup = backup/ape\n'
                 'mesh = LINEMOD/ape/ape.ply\ntr_range = LINEMOD/ape/training_range.txt\nname = ape\ndiam = 0.103\n'

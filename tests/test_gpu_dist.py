@@ -117,7 +117,14 @@ def _dp_worker(rank, world, port, q):
     torch.cuda.synchronize()
     out['running_single'] = [b.detach().cpu().clone() for n, b in model.named_buffers() if 'running' in n]
     out['local_grads_single'] = [p.grad.detach().cpu().clone() for p in model.parameters()]
-    q.put((rank, out))
+    # plain numpy through the queue (torch tensors travel as shared-memory handles that die with this process)
+    def np_tree(v):
+        if torch.is_tensor(v):
+            return v.contiguous().numpy().copy()
+        if isinstance(v, list):
+            return [np_tree(u) for u in v]
+        return v
+    q.put((rank, {k: np_tree(v) for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,7 +142,13 @@ def test_data_parallel_two_ranks_model_level():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    a, b = res[0], res[1]
+    def t_tree(v):
+        if isinstance(v, np.ndarray):
+            return torch.from_numpy(v)
+        if isinstance(v, list) and v and isinstance(v[0], np.ndarray):
+            return [torch.from_numpy(u) for u in v]
+        return v
+    a, b = ({k: t_tree(v) for k, v in res[r].items()} for r in (0, 1))
     # (a) SUM of the two local flat gradients, exactly (one fp32 addition per element), identical on both ranks
     want = a['local_flat'] + b['local_flat']
     assert torch.equal(a['reduced_flat_one_bucket'], want) and torch.equal(b['reduced_flat_one_bucket'], want)

@@ -433,3 +433,80 @@ def test_conv_plan_is_an_argument_two_threads_two_plans():
     torch.cuda.synchronize()
     for got, want in zip(bufs, serial):
         assert torch.equal(got[0], want)
+
+
+@pytest.mark.parametrize("B,H,W,Cdy,Cdx,R,plan", [
+    (4, 13, 13, 64, 128, 3, 0),            # direct epilogue, 128 x 128 / 64 x 128 tiles
+    (4, 13, 13, 128, 64, 1, 0),            # 1 x 1, 128 x 64 tiles
+    (16, 13, 13, 512, 256, 3, 12834),      # split-K x3: the sums come out of splitk_reduce_kernel
+    (16, 52, 52, 128, 256, 3, 306413),     # hybrid launch: un-split tiles (epilogue) + tail tiles (reduce kernel)
+    (2, 13, 13, 20, 1024, 1, 0),           # the head's data gradient (20 channels: register-staged kernel)
+])
+def test_conv_dgrad_with_fused_bn_backward_reductions(B, H, W, Cdy, Cdx, R, plan):
+    """ssp_conv_dgrad_bnbwd = ssp_conv_dgrad + the (sum dy, sum dy * xhat) reductions of the producing block, and
+    ssp_bn_act_bwd_partials finishes that block: gradient, dgamma / dbeta and dx against torch autograd (fp64) of
+    leaky(batch_norm(raw)) fed the same upstream gradient, and against the two-pass ssp_bn_act_bwd."""
+    G, _lib = _imports()
+    rs = np.random.RandomState(Cdy + Cdx + R)
+    M = B * H * W
+    dy = torch.from_numpy(rs.standard_normal((B, Cdy, H, W)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((Cdy, Cdx, R, R)) / np.sqrt(Cdy * R * R)).astype(np.float32))
+    raw = torch.from_numpy((rs.standard_normal((B, Cdx, H, W)) * 1.5 + 0.3).astype(np.float32))   # the producer's conv output
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, Cdx).astype(np.float32))
+    beta = torch.from_numpy((rs.standard_normal(Cdx) * 0.2).astype(np.float32))
+    # reference: g = conv_transpose-style data gradient of y = conv(a, wt); then BN + leaky backward in double
+    a = torch.zeros(B, Cdx, H, W, requires_grad=True)
+    F.conv2d(a, wt, None, padding=R // 2).backward(dy)
+    g_ref = a.grad.double()
+    rawd = raw.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    out = F.leaky_relu(F.batch_norm(rawd, None, None, gd, bd, True, 0.1, 1e-4), 0.1)
+    out.backward(g_ref)
+    coutp = (Cdy + 3) // 4 * 4
+    dyp = torch.zeros(B, coutp, H, W)
+    dyp[:, :Cdy] = dy
+    dyd = G.to_nhwc(dyp)
+    wd = G.pack_dgrad(wt, coutp)
+    rawd_dev = G.to_nhwc(raw)
+    mean = raw.double().mean(dim=(0, 2, 3))
+    var = raw.double().var(dim=(0, 2, 3), unbiased=False)
+    istd = 1.0 / torch.sqrt(var + 1e-4)
+    vec = torch.stack([mean, istd, gamma.double() * istd, beta.double() - mean * gamma.double() * istd]).float().to(G.dev())
+    tm = _lib.query('ssp_conv_stats_tile_m', B, H, W, coutp, Cdx, R, plan)
+    ntile = (M + tm - 1) // tm
+    wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cdx, R, plan))
+    ws = torch.empty(wsn, device=G.dev())
+    partial = torch.full((ntile * Cdx * 2,), float('nan'), device=G.dev())
+    gx = torch.full((M, Cdx), float('nan'), device=G.dev())
+    _lib.call('ssp_conv_dgrad_bnbwd', dyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), B, H, W, coutp, Cdx, coutp, Cdx, R,
+              plan, ws.data_ptr(), wsn, rawd_dev.data_ptr(), Cdx, vec[2].data_ptr(), vec[3].data_ptr(),
+              vec[0].data_ptr(), vec[1].data_ptr(), 0.1, partial.data_ptr(), G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(gx, B, Cdx, H, W).numpy(), g_ref.numpy()) < TOL
+    ps = partial.cpu().double().view(ntile, Cdx, 2).sum(0)
+    assert not torch.isnan(ps).any()
+    assert rel_err(ps[:, 0].numpy(), bd.grad.numpy()) < TOL                 # sum dy = dbeta
+    assert rel_err(ps[:, 1].numpy(), gd.grad.numpy()) < TOL                 # sum dy * xhat = dgamma
+    # finish the block from the partials, in place over the raw output (as Plan.backward does)
+    out_vec = torch.zeros(4, Cdx, device=G.dev())
+    dx1 = rawd_dev.clone()
+    _lib.call('ssp_bn_act_bwd_partials', dx1.data_ptr(), Cdx, gx.data_ptr(), Cdx, dx1.data_ptr(), Cdx, vec[2].data_ptr(),
+              vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), Cdx, B, H, W, 0.1, 1, partial.data_ptr(), ntile,
+              out_vec[0].data_ptr(), out_vec[1].data_ptr(), out_vec[2].data_ptr(), out_vec[3].data_ptr(), G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(dx1, B, Cdx, H, W).numpy(), rawd.grad.numpy()) < TOL
+    assert rel_err(out_vec[0].cpu().numpy(), gd.grad.numpy()) < TOL and rel_err(out_vec[1].cpu().numpy(), bd.grad.numpy()) < TOL
+    # and the two-pass form on the same inputs
+    nblk = _lib.query('ssp_bn_bwd_blocks')
+    p2 = torch.empty(nblk * Cdx * 2, device=G.dev())
+    out2 = torch.zeros(4, Cdx, device=G.dev())
+    dx2 = rawd_dev.clone()
+    _lib.call('ssp_bn_act_bwd', dx2.data_ptr(), Cdx, gx.data_ptr(), Cdx, dx2.data_ptr(), Cdx, vec[2].data_ptr(),
+              vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), Cdx, B, H, W, 0, 0.1, 1, p2.data_ptr(),
+              out2[0].data_ptr(), out2[1].data_ptr(), out2[2].data_ptr(), out2[3].data_ptr(), G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(dx1.cpu().numpy(), dx2.cpu().numpy()) < 1e-5
+    with pytest.raises(_lib.SspError):       # no silent fall-through: the fused form needs its output buffer
+        _lib.call('ssp_conv_dgrad_bnbwd', dyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), B, H, W, coutp, Cdx, coutp, Cdx,
+                  R, plan, ws.data_ptr(), wsn, rawd_dev.data_ptr(), Cdx, vec[2].data_ptr(), vec[3].data_ptr(),
+                  vec[0].data_ptr(), vec[1].data_ptr(), 0.1, None, G.stream())
