@@ -64,11 +64,13 @@ int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, in
  *   partial[tile][c] = (sum over the tile's pixels of dy, of dy * xhat),  dy = g * leaky'(scale*raw + shift),
  *   xhat = (raw - mean) * invstd;   tile = pixel / ssp_conv_stats_tile_m(B,H,W,Cout_dy,Cin_dx,R,plan),
  * i.e. what ssp_bn_act_bwd's reduce pass would re-read g and raw for; ssp_bn_act_bwd_partials finishes the block.
- * partial: ceil(B*H*W / tile_m) * Cin_dx * 2 floats.  Cin_dx % 4 == 0. */
+ * partial: partial_rows * Cin_dx * 2 floats.  A launch with ntile = ceil(B*H*W / tile_m) <= partial_rows tiles stores row
+ * `tile` plainly (deterministic); a launch with more tiles folds tile t into row t % partial_rows with fp32 atomic adds,
+ * and the buffer must then be ZERO on entry (ssp_bn_act_bwd_partials with zero_after = 1 leaves it so).  Cin_dx % 4 == 0. */
 int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx,
                          int lddy, int lddx, int R, int plan, float* workspace, int64_t workspace_floats,
                          const float* raw, int ldraw, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, float slope, float* partial, void* stream);
+                         const float* invstd, float slope, float* partial, int partial_rows, void* stream);
 
 /* filter gradient: dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]; dw is [Cout][R*R][Cin] packed and must be
  * zeroed by the caller (split reduction uses fp32 atomics). */
@@ -98,8 +100,8 @@ int ssp_bn_act_bwd(const float* x, int ldx, const float* g, int ldg, float* dx, 
  * dgamma / dbeta (and c1 / c2), then dx (may alias x) = scale * (dy - c1 - xhat * c2) */
 int ssp_bn_act_bwd_partials(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
                             const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
-                            float slope, int training, const float* partial, int npartial, float* dgamma, float* dbeta,
-                            float* c1, float* c2, void* stream);
+                            float slope, int training, float* partial, int npartial, int zero_after, float* dgamma,
+                            float* dbeta, float* c1, float* c2, void* stream);
 /* out[c] = sum_p g[p][c]  (bias gradient of the linear head conv) */
 int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream);
 

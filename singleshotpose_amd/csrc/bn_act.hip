@@ -247,28 +247,43 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
   }
 }
 
-// one wave per channel: fp64 sum of the per-block partials
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                              double inv_n, int training, float* dgamma, float* dbeta,
-                                                              float* c1, float* c2) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int t = lane; t < nblk; t += 64) {
-    const float* s = partial + ((int64_t)t * C + c) * 2;
-    a += (double)s[0];
-    b += (double)s[1];
+// fp64 sum of the per-block (or per-tile) partial pairs.  One workgroup per 4 channels: a partial row holds their 8
+// floats contiguously (two float4), thread = (row lane 0..127, float4 half), fp64 accumulation, LDS tree over the row
+// lanes.  zero_after: the rows are cleared once read (the fused data-gradient path accumulates into them with atomics
+// when it has more tiles than rows, and expects zeros the next time).
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(float* __restrict__ partial, int nblk, int C,
+                                                              double inv_n, int training, int zero_after, float* dgamma,
+                                                              float* dbeta, float* c1, float* c2) {
+  const int tid = threadIdx.x, half = tid & 1, lane = tid >> 1;
+  const int c0 = blockIdx.x * 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int t = lane; t < nblk; t += 128) {
+    float* s = partial + ((int64_t)t * C + c0) * 2 + half * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s);
+    acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
+    if (zero_after) *reinterpret_cast<f32x4*>(s) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off);
-    b += __shfl_xor(b, off);
+  __shared__ double red[256][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[tid][k] = acc[k];
+  __syncthreads();
+  for (int off = 128; off >= 2; off >>= 1) {       // keeps the float4 half (tid & 1) apart
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[tid][k] += red[tid + off][k];
+    }
+    __syncthreads();
   }
-  if (lane == 0) {
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)b;
-    c1[c] = training ? (float)(a * inv_n) : 0.f;
-    c2[c] = training ? (float)(b * inv_n) : 0.f;
+  if (tid < 4) {
+    // channel c0 + tid: (sum dy, sum dy*xhat) = floats 2*tid, 2*tid+1 of the 8 -> half = tid >> 1, k = (tid & 1) * 2
+    const int c = c0 + tid;
+    if (c < C) {
+      const double a = red[tid >> 1][(tid & 1) * 2], b = red[tid >> 1][(tid & 1) * 2 + 1];
+      dbeta[c] = (float)a;
+      dgamma[c] = (float)b;
+      c1[c] = training ? (float)(a * inv_n) : 0.f;
+      c2[c] = training ? (float)(b * inv_n) : 0.f;
+    }
   }
 }
 
@@ -417,7 +432,7 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
                        scale, shift, mean, invstd, C, B, H, W, pool, slope, partial, (float*)nullptr, (float*)nullptr);
     SSP_CHECK_LAUNCH("bn_act_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, nblk, C,
-                       1.0 / ((double)B * H * W), training, dgamma, dbeta, c1, c2);
+                       1.0 / ((double)B * H * W), training, 0, dgamma, dbeta, c1, c2);
     SSP_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(total)), dim3(256), 0, stream, x, ldx, g, ldg, dx, lddx,
                        scale, shift, mean, invstd, c1, c2, 1.f, C, B, H, W, pool, slope);
@@ -430,14 +445,15 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
 // sum dy * xhat) pair per M tile and channel): fp64 finalize over the tiles, then the apply pass.  Un-pooled blocks only.
 int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx,
                                    const float* scale, const float* shift, const float* mean, const float* invstd,
-                                   int C, int B, int H, int W, float slope, int training, const float* partial,
-                                   int npartial, float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream) {
+                                   int C, int B, int H, int W, float slope, int training, float* partial,
+                                   int npartial, int zero_after, float* dgamma, float* dbeta, float* c1, float* c2,
+                                   hipStream_t stream) {
   SSP_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && lddx % 4 == 0, "bn_act_bwd_partials: C and strides must be multiples of 4");
-  SSP_CHECK_ARG(partial != nullptr && npartial > 0, "bn_act_bwd_partials: no partial sums");
+  SSP_CHECK_ARG(partial != nullptr && npartial > 0 && (((uintptr_t)partial) & 15) == 0, "bn_act_bwd_partials: no (aligned) partial sums");
   const int64_t npix = (int64_t)B * H * W;
   SspProfScope prof(SSP_PROF_BN_ACT, stream, 4.0 * C * 3.0 * (double)npix);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, npartial, C,
-                     1.0 / (double)npix, training, dgamma, dbeta, c1, c2);
+                     1.0 / (double)npix, training, zero_after, dgamma, dbeta, c1, c2);
   SSP_CHECK_LAUNCH("bn_bwd_finalize");
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(elem_grid(npix * (C / 4))), dim3(256), 0, stream, x, ldx, g, ldg, dx,
                      lddx, scale, shift, mean, invstd, c1, c2, 1.f, C, B, H, W, 0, slope);

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bn_shift,
                                                             const float* __restrict__ bn_mean,
                                                             const float* __restrict__ bn_invstd, float bn_slope,
-                                                            float* bn_partial) {
+                                                            float* bn_partial, int bn_nslot, int ntile_all) {
   // rows [row0, M) (row0 a multiple of tile_m); workspace row m sits at m - row0, split stride (M - row0) rows
   const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
   const int c = blockIdx.y * 64 + gl * 4;
@@ -364,9 +364,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
       if (ch < Cout) {
         float a = 0.f, b = 0.f;
         for (int w = 0; w < 16; ++w) { a += red[w][q][1 + k]; b += red[w][q][5 + k]; }
-        float* dst = bn_partial + ((int64_t)(m0 / tile_m) * Cout + ch) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        const int t = m0 / tile_m;
+        if (ntile_all > bn_nslot) {
+          float* dst = bn_partial + ((int64_t)(t % bn_nslot) * Cout + ch) * 2;
+          atomicAdd(dst, a);
+          atomicAdd(dst + 1, b);
+        } else {
+          float* dst = bn_partial + ((int64_t)t * Cout + ch) * 2;
+          dst[0] = a;
+          dst[1] = b;
+        }
       }
     }
     return;
@@ -486,7 +493,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.probe = 0;
   a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;
   a.bn_raw = nullptr; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr; a.bn_partial = nullptr;
-  a.bn_ld = 0; a.bn_slope = 1.f;
+  a.bn_ld = 0; a.bn_slope = 1.f; a.bn_nslot = 1;
   if (bnb != nullptr && bnb->partial != nullptr) {
     SSP_CHECK_ARG(accumulate == 0 && bias == nullptr && stats == nullptr && escale == nullptr,
                   "conv: the fused BatchNorm-backward reductions need a plain (non-accumulating) data-gradient launch");
@@ -497,6 +504,8 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
                   "conv: bad BatchNorm-backward operands (16-byte aligned, Cout %% 4 == 0, ldraw >= Cout)");
     a.bn_raw = bnb->raw; a.bn_ld = bnb->ldraw; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift; a.bn_mean = bnb->mean;
     a.bn_invstd = bnb->invstd; a.bn_slope = bnb->slope; a.bn_partial = bnb->partial;
+    SSP_CHECK_ARG(bnb->nslot >= 1, "conv: the BatchNorm-backward partial buffer needs at least one row");
+    a.bn_nslot = bnb->nslot;
   }
   const IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
   a.ksplit = pl.ksplit;
@@ -561,12 +570,13 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   if (pl.ksplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
                        bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, 0, a.bn_raw, a.bn_ld, a.bn_scale,
-                       a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial);
+                       a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot, ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce");
   } else if (a.tail_ks > 1) {     // hybrid launch: only the tail rows were left as partials
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
                        a.tail_ks, out, ldout, bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, a.ws_row0,
-                       a.bn_raw, a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial);
+                       a.bn_raw, a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot,
+                       ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce(tail)");
   }
   return SSP_OK;

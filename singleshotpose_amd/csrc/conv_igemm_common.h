@@ -35,7 +35,9 @@ struct ConvArgs {
   const float* bn_shift;
   const float* bn_mean;
   const float* bn_invstd;
-  float* bn_partial;   // [ntile_m][Cout][2] or nullptr
+  float* bn_partial;   // [min(ntile_m, bn_nslot)][Cout][2] or nullptr
+  int bn_nslot;        // launches with more M tiles than rows fold tile t into row t % bn_nslot with fp32 atomics (the rows
+                       // must be zero on entry); fewer tiles: one plain store per (tile, channel), deterministic
   int bn_ld;
   float bn_slope;
 };
@@ -171,9 +173,15 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
         float a = smem[col * 2 + 0], b = smem[col * 2 + 1];
 #pragma unroll
         for (int w = 1; w < WM; ++w) { a += smem[(w * BN + col) * 2 + 0]; b += smem[(w * BN + col) * 2 + 1]; }
-        float* dst = p.bn_partial + ((int64_t)tile_m * p.Cout + n) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        if (p.ntile_m > p.bn_nslot) {
+          float* dst = p.bn_partial + ((int64_t)(tile_m % p.bn_nslot) * p.Cout + n) * 2;
+          atomicAdd(dst, a);
+          atomicAdd(dst + 1, b);
+        } else {
+          float* dst = p.bn_partial + ((int64_t)tile_m * p.Cout + n) * 2;
+          dst[0] = a;
+          dst[1] = b;
+        }
       }
     }
   }

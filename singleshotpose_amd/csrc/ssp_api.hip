@@ -30,8 +30,9 @@ int ssp_bn_act_bwd_launch(const float* x, int ldx, const float* g, int ldg, floa
                           float* c2, hipStream_t stream);
 int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx,
                                    const float* scale, const float* shift, const float* mean, const float* invstd,
-                                   int C, int B, int H, int W, float slope, int training, const float* partial,
-                                   int npartial, float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream);
+                                   int C, int B, int H, int W, float slope, int training, float* partial,
+                                   int npartial, int zero_after, float* dgamma, float* dbeta, float* c1, float* c2,
+                                   hipStream_t stream);
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
 int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float dampening,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
@@ -182,8 +183,8 @@ int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, in
 int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx,
                          int lddy, int lddx, int R, int plan, float* workspace, int64_t workspace_floats,
                          const float* raw, int ldraw, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, float slope, float* partial, void* stream) {
-  SspBnBwdFuse f = {raw, ldraw, scale, shift, mean, invstd, slope, partial};
+                         const float* invstd, float slope, float* partial, int partial_rows, void* stream) {
+  SspBnBwdFuse f = {raw, ldraw, scale, shift, mean, invstd, slope, partial, partial_rows};
   if (partial == nullptr) {
     ssp_set_error("conv_dgrad_bnbwd: partial must not be NULL (use ssp_conv_dgrad)");
     return SSP_ERR_ARG;
@@ -193,10 +194,10 @@ int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int
 }
 int ssp_bn_act_bwd_partials(const float* x, int ldx, const float* g, int ldg, float* dx, int lddx, const float* scale,
                             const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
-                            float slope, int training, const float* partial, int npartial, float* dgamma, float* dbeta,
-                            float* c1, float* c2, void* stream) {
+                            float slope, int training, float* partial, int npartial, int zero_after, float* dgamma,
+                            float* dbeta, float* c1, float* c2, void* stream) {
   return ssp_bn_act_bwd_partials_launch(x, ldx, g, ldg, dx, lddx, scale, shift, mean, invstd, C, B, H, W, slope, training,
-                                        partial, npartial, dgamma, dbeta, c1, c2, (hipStream_t)stream);
+                                        partial, npartial, zero_after, dgamma, dbeta, c1, c2, (hipStream_t)stream);
 }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,

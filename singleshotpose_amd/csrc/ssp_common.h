@@ -77,7 +77,8 @@ struct SspBnBwdFuse {
   const float* mean;
   const float* invstd;
   float slope;
-  float* partial;        // out: [ceil(M / tile_m)][C][2] = (sum dy, sum dy * xhat) per M tile
+  float* partial;        // out: [min(ntile, nslot)][C][2] = (sum dy, sum dy * xhat) per M tile (folded modulo nslot)
+  int nslot;
 };
 
 static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

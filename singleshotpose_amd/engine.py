@@ -342,8 +342,9 @@ class Plan(object):
                 continue
             tm = _lib.query('ssp_conv_stats_tile_m', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.plan_dgrad)
             ntile = (cs.M + tm - 1) // tm
+            rows = min(ntile, 1024)       # more tiles than rows: folded with atomics into a buffer that stays zeroed
             cs.bn_fuse_src = scs
-            scs.bnp = (torch.empty(ntile * scs.cout * 2, dtype=torch.float32, device=self.device), ntile)
+            scs.bnp = (torch.zeros(rows * scs.cout * 2, dtype=torch.float32, device=self.device), rows, ntile > rows)
 
     def _repack_dgrad(self, cs, stream):
         src = cs.conv.weight.detach()
@@ -745,11 +746,11 @@ class Plan(object):
                         partial = self.bn_partial.data_ptr()
                     if cs.ind in fused_stats:
                         # the two reductions came out of the consumer's data-gradient launch: finalize + apply only
-                        ptile, ntile = cs.bnp
+                        ptile, rows, folded = cs.bnp
                         call('ssp_bn_act_bwd_partials', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(),
                              cs.ldraw, v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B,
-                             cs.H, cs.W, cs.slope, 1 if training else 0, ptile.data_ptr(), ntile, dg_ptr, db_ptr,
-                             v[4].data_ptr(), v[5].data_ptr(), st)
+                             cs.H, cs.W, cs.slope, 1 if training else 0, ptile.data_ptr(), rows, 1 if folded else 0,
+                             dg_ptr, db_ptr, v[4].data_ptr(), v[5].data_ptr(), st)
                     else:
                         call('ssp_bn_act_bwd', cs.raw.data_ptr(), cs.ldraw, g.ptr, g.ld, cs.raw.data_ptr(), cs.ldraw,
                              v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), cs.coutp, B, cs.H, cs.W,
@@ -788,7 +789,7 @@ class Plan(object):
                         call('ssp_conv_dgrad_bnbwd', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W,
                              cs.coutp, cs.cin, dy_ld, gin.ld, cs.k, cs.plan_dgrad, self.ws.data_ptr(), self.ws_floats,
                              scs.raw.data_ptr(), scs.ldraw, sv[2].data_ptr(), sv[3].data_ptr(), sv[0].data_ptr(),
-                             sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), st)
+                             sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), scs.bnp[1], st)
                         fused_stats.add(src)
                     else:
                         call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
