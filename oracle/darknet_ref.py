@@ -71,7 +71,7 @@ def reorg_ref(x, stride=2):
     return x.view(B, s * s * C, H // s, W // s)
 
 
-def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None):
+def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None, tape=None):
     """Runs the layer list on CPU tensors.  `state` entries may require grad; running stats are updated in place
     when training.  Returns the raw head (and every layer output when keep=True).
 
@@ -81,7 +81,9 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
     downstream - batch statistics, leaky sign, max-pool arg-max - is then decided on identical numbers on both sides, so
     whole-network gradients can be compared at a strict tolerance instead of the fp32-vs-fp64 envelope that independent
     forward passes need (rounding flips max-pool / leaky decisions and the flips propagate).
-    raws (dict, optional): filled with this function's own convolution outputs {layer index: tensor (detached)}."""
+    raws (dict, optional): filled with this function's own convolution outputs {layer index: tensor (detached)}.
+    tape (dict, optional): filled with {layer index: (conv input, conv output node with retain_grad, padding)} so a
+    caller can re-evaluate a filter gradient in float64 after backward (step_check.py: ill-conditioned sums)."""
     outputs = {}
     for ind, b in enumerate(blocks[1:]):
         t = b['type']
@@ -89,11 +91,15 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
             e = state[ind]
             k = int(b['size'])
             pad = (k - 1) // 2 if int(b['pad']) else 0
+            x_in = x
             x = F.conv2d(x, e['weight'], e.get('bias'), stride=int(b['stride']), padding=pad)
             if raws is not None:
                 raws[ind] = x.detach()
             if raw_override is not None and ind in raw_override:
                 x = raw_override[ind] + (x - x.detach())
+            if tape is not None and x.requires_grad:
+                x.retain_grad()
+                tape[ind] = (x_in, x, pad)
             if 'bn_weight' in e:
                 x = F.batch_norm(x, e['running_mean'], e['running_var'], e['bn_weight'], e['bn_bias'], training,
                                  momentum, 1e-4)
