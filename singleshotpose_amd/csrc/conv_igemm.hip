@@ -449,7 +449,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R, int plan_code) {
     if (Cin % 16 == 0 && Cout % 4 == 0 && niter / (variant - 68) >= 8) pl.ksplit = variant - 68;
     return pl;
   }
-  if (variant != 0 && variant != 30 && variant != 50 && variant != 61 && variant != 62) return pl;   // experiment variants: plain 128x128, no split
+  if (variant != 0 && variant != 30 && variant != 50 && variant != 61 && variant != 62 && variant != 63) return pl;   // experiment variants: plain 128x128, no split
   const int64_t t128 = (int64_t)ssp_cdiv(M, 128) * ssp_cdiv(Cout, 128);
   const int64_t t64 = (int64_t)ssp_cdiv(M, 64) * ssp_cdiv(Cout, 128);
   if (t128 > 1400) return pl;
@@ -490,7 +490,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
-  a.probe = 0;
+  a.probe = ssp_option(SSP_OPT_IGEMM_VARIANT) == 63 ? 2 : 0;      // 63: A/B switch - the generic (predicated) epilogue everywhere
   a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;
   a.bn_raw = nullptr; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr; a.bn_partial = nullptr;
   a.bn_ld = 0; a.bn_slope = 1.f; a.bn_nslot = 1;

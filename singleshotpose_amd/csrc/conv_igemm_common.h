@@ -162,7 +162,134 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
       }
     }
   };
-  if (p.bn_partial != nullptr) body(std::false_type{}, std::true_type{});       // never with accumulate (checked on the host)
+  // ---- lean form for tiles whose BM rows all exist (every tile but the last tile row) ----
+  // The fp32 MFMA runs on the SIMD's vector lanes: every VALU instruction of the epilogue is matrix time lost, and the
+  // generic form above spends ~20 of them per stored element (64-bit address arithmetic and an exec-mask branch for the
+  // m < M && n < Cout test): ~5 k VALU cycles per wave against 37 k - 74 k cycles of MFMA in the K = 288 / 576 layers.
+  // Here a tile is addressed through a buffer descriptor on its first row: the lane's byte offset is fixed (columns
+  // beyond Cout carry an out-of-range offset and are dropped by the buffer unit), the row steps are SCALAR offsets
+  // (SALU), so a stored element costs one buffer_store_dword plus - only when there is an affine / activation /
+  // accumulate / BatchNorm-backward term - the arithmetic itself.
+  auto body_fast = [&](auto accum_tag, auto bnb_tag, auto ident_tag) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool ACCUM = decltype(accum_tag)::value;
+    constexpr bool BNB = decltype(bnb_tag)::value;
+    constexpr bool IDENT = decltype(ident_tag)::value;     // no bias, no per-channel scale, no activation
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + (int64_t)m0 * p.ldout), 0, BM * p.ldout * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = rs_o;
+    if constexpr (BNB)
+      rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn_raw + (int64_t)m0 * p.bn_ld), 0, BM * p.bn_ld * 4, 0x00020000);
+    const int ld4 = p.ldout * 4, ldx4 = p.bn_ld * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + li;
+      const bool n_ok = n < p.Cout;
+      const unsigned voff = n_ok ? (unsigned)(((wm * WTM + 4 * lh) * p.ldout + n) * 4) : 0x80000000u;
+      float bias = 0.f, esc = 1.f;
+      if constexpr (!IDENT) {
+        bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+        esc = (p.escale != nullptr && n_ok) ? p.escale[n] : 1.f;
+      }
+      float b_sc = 0.f, b_sh = 0.f, b_mu = 0.f, b_is = 0.f, s1 = 0.f, s2 = 0.f;
+      unsigned voffx = 0x80000000u;
+      if constexpr (BNB) {
+        if (n_ok) {
+          b_sc = p.bn_scale[n]; b_sh = p.bn_shift[n]; b_mu = p.bn_mean[n]; b_is = p.bn_invstd[n];
+          voffx = (unsigned)(((wm * WTM + 4 * lh) * p.bn_ld + n) * 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        // Row offsets walk in a running SCALAR (rows r&3 + 8*(r>>2): steps of 1,1,1,5 rows).  The empty asm makes the
+        // value opaque, so the compiler keeps ONE live SGPR and an s_add per element instead of hoisting all 16 * TM *
+        // TN products in front of the four code paths (which spilled ~300 SGPRs into VGPR lanes: v_readlane per store).
+        float xr[16], prev[16];
+        if constexpr (BNB) {
+          int so = i * 32 * ldx4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            asm volatile("" : "+s"(so));
+            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, voffx, so, 0));
+            so += ((r & 3) == 3) ? 5 * ldx4 : ldx4;
+          }
+        }
+        if constexpr (ACCUM) {
+          int so = i * 32 * ld4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            asm volatile("" : "+s"(so));
+            prev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, voff, so, 0));
+            so += ((r & 3) == 3) ? 5 * ld4 : ld4;
+          }
+        }
+        int so = i * 32 * ld4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          if constexpr (!IDENT) {
+            v = v * esc + bias;
+            v = v > 0.f ? v : v * p.act_slope;
+          }
+          if constexpr (ACCUM) v += prev[r];
+          asm volatile("" : "+s"(so));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, voff, so, 0);
+          so += ((r & 3) == 3) ? 5 * ld4 : ld4;
+          if constexpr (BNB) {
+            const float y = xr[r] * b_sc + b_sh;
+            const float dyv = y > 0.f ? v : v * p.bn_slope;
+            s1 += dyv;
+            s2 += dyv * ((xr[r] - b_mu) * b_is);
+          }
+        }
+      }
+      if constexpr (BNB) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const int col = wn * WTN + j * 32 + li;
+        if (lh == 0) {
+          smem[(wm * BN + col) * 2 + 0] = s1;
+          smem[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+      if (p.stats != nullptr) {
+        // every one of this lane's 16 * TM rows exists: count is a constant
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        float cnt = n_ok ? (float)(16 * TM) : 0.f;
+        float mean = n_ok ? sum * (1.f / (float)(16 * TM)) : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[i][j][r] - mean;
+            m2 += d * d;
+          }
+        if (!n_ok) m2 = 0.f;
+        float ocnt = __shfl_xor(cnt, 32), omean = __shfl_xor(mean, 32), om2 = __shfl_xor(m2, 32);
+        chan_combine(cnt, mean, m2, ocnt, omean, om2);
+        const int col = wn * WTN + j * 32 + li;
+        if (lh == 0) {
+          smem[(wm * BN + col) * 3 + 0] = cnt;
+          smem[(wm * BN + col) * 3 + 1] = mean;
+          smem[(wm * BN + col) * 3 + 2] = m2;
+        }
+      }
+    }
+#endif
+  };
+  const bool interior = (m0 + BM <= p.M) && ((int64_t)BM * max(p.ldout, p.bn_ld) * 4 < (1ll << 31)) && p.probe != 2;
+  const bool ident = p.bias == nullptr && p.escale == nullptr && p.act_slope == 1.f;
+  if (interior) {
+    if (p.bn_partial != nullptr) body_fast(std::false_type{}, std::true_type{}, std::true_type{});   // dgrad: plain output
+    else if (p.accumulate) body_fast(std::true_type{}, std::false_type{}, std::true_type{});
+    else if (ident) body_fast(std::false_type{}, std::false_type{}, std::true_type{});
+    else body_fast(std::false_type{}, std::false_type{}, std::false_type{});
+  } else if (p.bn_partial != nullptr) body(std::false_type{}, std::true_type{});       // never with accumulate (checked on the host)
   else if (p.accumulate) body(std::true_type{}, std::false_type{});
   else body(std::false_type{}, std::false_type{});
   if (p.bn_partial != nullptr) {

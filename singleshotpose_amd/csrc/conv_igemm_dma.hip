@@ -279,7 +279,7 @@ static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
   const int niter_total = a.R * a.R * (a.Cin / 16);
-  a.probe = ssp_option(SSP_OPT_IGEMM_VARIANT) == 60 ? 1 : 0;
+  if (ssp_option(SSP_OPT_IGEMM_VARIANT) == 60) a.probe = 1;
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   const int lds_bytes = NSLOT * (BM + BN) * 64 + ((BN % 64) ? 1024 : 0);

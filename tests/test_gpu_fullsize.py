@@ -24,8 +24,8 @@ GRAD_TOL = 3e-4      # whole-network gradients, decision-frozen (same bar the 96
 def _report(tag, res):
     from oracle.step_check import summarize
     worst = sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:3]
-    print('%s: %s | worst grads %s | plans %s' % (tag, summarize(res), worst,
-                                                   [(i, f, d) for i, f, d in res['plans'] if f or d]))
+    print('%s: %s | worst grads %s | fp64-oracle fallbacks %s | plans %s' % (
+        tag, summarize(res), worst, res.get('grad_fp64_oracle', {}), [(i, f, d) for i, f, d in res['plans'] if f or d]))
 
 
 def _assert_step(res):
