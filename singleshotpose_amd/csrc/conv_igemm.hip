@@ -489,6 +489,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   a.in = in; a.wt = wt; a.out = out; a.bias = bias; a.stats = stats; a.escale = escale; a.act_slope = act_slope;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldin = ldin; a.ldout = ldout; a.R = R;
   a.M = B * H * W; a.accumulate = accumulate;
+  a.divW = ssp_fastdiv((unsigned)W); a.divH = ssp_fastdiv((unsigned)H);
   a.xcd_remap = ssp_option(SSP_OPT_IGEMM_XCD);
   a.probe = ssp_option(SSP_OPT_IGEMM_VARIANT) == 63 ? 2 : 0;      // 63: A/B switch - the generic (predicated) epilogue everywhere
   a.tail_begin = 0; a.tail_ks = 0; a.tail_it_per_split = 0; a.ws_row0 = 0; a.ws_rows = a.M; a.col_major = 0;

@@ -24,6 +24,7 @@ struct ConvArgs {
   int tail_begin, tail_ks, tail_it_per_split;
   int ws_row0, ws_rows;
   int col_major;       // tile order inside a launch: tile_m fastest (workgroups resident on one XCD share a filter slab)
+  SspFastDiv divW, divH;   // m -> (x, y) of a tile row without run-time integer division
   int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
   // Data-gradient launches only: BatchNorm-backward reductions of the block that PRODUCED the activation whose gradient
   // this launch writes (out = g = dL/d leaky(BN(raw))).  With bn_partial set, the finishing pass (tile epilogue or
@@ -286,7 +287,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
   const bool ident = p.bias == nullptr && p.escale == nullptr && p.act_slope == 1.f;
   if (interior) {
     if (p.bn_partial != nullptr) body_fast(std::false_type{}, std::true_type{}, std::true_type{});   // dgrad: plain output
-    else if (p.accumulate) body_fast(std::true_type{}, std::false_type{}, std::true_type{});
+    else if (p.accumulate && ident) body_fast(std::true_type{}, std::false_type{}, std::true_type{});
+    else if (p.accumulate) body_fast(std::true_type{}, std::false_type{}, std::false_type{});
     else if (ident) body_fast(std::false_type{}, std::false_type{}, std::true_type{});
     else body_fast(std::false_type{}, std::false_type{}, std::false_type{});
   } else if (p.bn_partial != nullptr) body(std::false_type{}, std::true_type{});       // never with accumulate (checked on the host)

@@ -125,8 +125,9 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
     const int m = m0 + row;
     const int chunk = lch ^ ((row >> 2) & 3);              // logical 16-byte chunk stored at physical position lch
     if (m < p.M) {
-      a_x[j] = m % p.W;
-      a_y[j] = (m / p.W) % p.H;
+      const unsigned q = ssp_div((unsigned)m, p.divW);       // m / W
+      a_x[j] = m - (int)q * p.W;
+      a_y[j] = (int)(q - ssp_div(q, p.divH) * (unsigned)p.H);   // (m / W) % H
     } else {
       a_x[j] = 0;
       a_y[j] = -(1 << 20);                                 // never inside the image

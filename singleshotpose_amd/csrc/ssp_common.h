@@ -81,6 +81,27 @@ struct SspBnBwdFuse {
   int nslot;
 };
 
+// Division of a non-negative 32-bit value by a launch-invariant divisor in ~5 VALU instructions (the compiler's
+// sequence for a run-time divisor is ~25; the conv kernels divide per tile row in their prologue, on the same lanes the
+// fp32 MFMA uses).  Round-up method: q = (t + ((n - t) >> 1)) >> (shr - 1), t = umulhi(n, mul); exact for 0 <= n < 2^32.
+struct SspFastDiv {
+  unsigned mul, shr, d;
+};
+static inline SspFastDiv ssp_fastdiv(unsigned d) {
+  SspFastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;      // ceil(log2 d)
+  f.shr = l;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned ssp_div(unsigned n, const SspFastDiv& f) {
+  if (f.shr == 0) return n;         // d == 1 (wave-uniform branch)
+  const unsigned t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.shr - 1);
+}
+
 static inline int ssp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Observed dispatch places workgroup b on XCD b%8 (MI355X_MICROARCH.md, "Workgroup dispatch").

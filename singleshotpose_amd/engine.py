@@ -376,13 +376,14 @@ class Plan(object):
         n_known = len(_TUNE_CACHE)
         # tile rows x split-K x ring depth; 3xxxxx / 2xxxxx = hybrid launches (whole resident waves un-split, the tiles of
         # the last partial wave split 3 / 2 ways over K)
-        cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814)
+        cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814,
+                 12823, 6423, 6424, 206414, 212813, 406413, 406414, 412813)
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
             return
-        def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x3 mid, none big)
+        def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x4 mid, none big)
             mc = cs.M * max(cs.coutp, cs.cinp)
-            return 9 * mc if mc <= (1 << 21) else (3 * mc if mc <= (1 << 25) else 1)
+            return 9 * mc if mc <= (1 << 21) else (4 * mc if mc <= (1 << 25) else 1)
         max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
         stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32) if which == 'fwd' else None
@@ -397,7 +398,8 @@ class Plan(object):
             best, best_t = 0, None
             # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
             # deep K splits put every CU on the weight stream
-            deep = (12864, 12894, 6464, 6494) if mn <= (1 << 21) else ()
+            deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4)) \
+                if mn <= (1 << 21) else ()
             for code in cands + deep:
                 if ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
