@@ -304,8 +304,35 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if (p.no_store && acc[0][0][0] != 12345.678f) return;
+  if (p.no_store == 1 && acc[0][0][0] != 12345.678f) return;
 
+  // Lean form (un-folded tiles whose BMO filters all exist): the tile's gradient rows are addressed through a buffer
+  // descriptor on dw[co0][tap][0]; the lane's byte offset is fixed (cins beyond Cin carry an out-of-range offset, the
+  // buffer unit drops them), the filter-row steps are SCALAR offsets - one buffer_atomic_add_f32 and one s_add per
+  // element, no 64-bit address arithmetic, no exec-mask branch on the lanes the MFMAs of the co-resident waves need.
+  const int64_t row_floats = (int64_t)taps * p.Cin;                       // floats between consecutive filters of dw
+  if (!FOLD && co0 + BMO <= p.Cout && (int64_t)BMO * row_floats * 4 < (1ll << 31) && p.no_store != 2) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dw + ((int64_t)co0 * taps + tap) * p.Cin), 0, (int)(BMO * row_floats * 4), 0x00020000);
+    const int row4 = (int)row_floats * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * WTN + (BVEC ? li * TN + j : j * 32 + li);
+      const int ci = ci0 + col;
+      const unsigned voff = (ci < p.Cin) ? (unsigned)(((wm * WTM + 4 * lh * TM) * (int)row_floats + ci) * 4) : SSP_OOB;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int so = i * row4;                      // filter row of element r: ((r&3) + 8*(r>>2)) * TM + i
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          asm volatile("" : "+s"(so));          // one live SGPR, one s_add per element (see conv_igemm_common.h)
+          (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rs, voff, so, 0);
+          so += (((r & 3) == 3) ? 5 : 1) * TM * row4;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -328,7 +355,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   a.ntile_co = ssp_cdiv(a.Cout, BMO);
   a.ntile_ci = ssp_cdiv(a.Cin, BNI);
   a.fold = FOLD ? BNI / a.Cin : 1;
-  a.no_store = ssp_option(SSP_OPT_WGRAD_VARIANT) == 9;
+  a.no_store = ssp_option(SSP_OPT_WGRAD_VARIANT) == 9 ? 1 : (ssp_option(SSP_OPT_WGRAD_VARIANT) == 11 ? 2 : 0);   // 11: generic epilogue (A/B)
   const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold);
   const int lds_bytes = NSLOT * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>;
