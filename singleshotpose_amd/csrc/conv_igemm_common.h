@@ -67,6 +67,30 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
   if (partial) {
     // split-K: raw partial tile to the workspace; bias / accumulate / BN statistics happen in splitk_reduce_kernel
     float* wsp = p.ws + ((int64_t)split * p.ws_rows - p.ws_row0) * p.Cout;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (m0 + BM <= p.M && (int64_t)BM * p.Cout * 4 < (1ll << 31) && p.probe != 2) {
+      // lean form (see body_fast below): buffer stores, fixed lane offset, scalar row steps
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(wsp + (int64_t)m0 * p.Cout), 0,
+                                                                          BM * p.Cout * 4, 0x00020000);
+      const int ld4 = p.Cout * 4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + li;
+        const unsigned voff = (n < p.Cout) ? (unsigned)(((wm * WTM + 4 * lh) * p.Cout + n) * 4) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          int so = i * 32 * ld4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            asm volatile("" : "+s"(so));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r]), rs, voff, so, 0);
+            so += ((r & 3) == 3) ? 5 * ld4 : ld4;
+          }
+        }
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WTN + j * 32 + li;
