@@ -1,7 +1,7 @@
 """Multi-object decode helpers - host-side mirror of multi_obj_pose_estimation/utils_multi.py.
 
-Everything utils.py offers, plus get_multi_region_boxes (utils_multi.py:266-382), bbox_iou (:125-156) and nms
-(:223-241).  The per-cell decode (sigmoid, grid offsets, softmax, arg-max) runs in ssp_region_decode_all; the
+Everything utils.py offers, plus get_multi_region_boxes (utils_multi.py:266-382) and bbox_iou (:125-156); `nms`
+(:223-241) has no caller on the pose path (valid_multi.py / train_multi.py never invoke it) and is not mirrored.  The per-cell decode (sigmoid, grid offsets, softmax, arg-max) runs in ssp_region_decode_all; the
 variable-length box lists are assembled on the host from that one device->host copy, with the reference's rules:
 threshold on det_conf (only_objectness) or det_conf*cls_max_conf; a fallback box of `correspondingclass` when no kept
 box has that class; `max_cls_conf` is NOT reset per image.
@@ -15,41 +15,28 @@ from . import _lib
 from .utils import *  # noqa: F401,F403
 
 
+def _span(lo_a, hi_a, lo_b, hi_b):
+    """Length of the overlap of two intervals (<= 0 when they are disjoint)."""
+    return min(hi_a, hi_b) - max(lo_a, lo_b)
+
+
 def bbox_iou(box1, box2, x1y1x2y2=False):
+    """Intersection over union of two boxes given as corners (x1, y1, x2, y2) or as centre + size (x, y, w, h) - the
+    helper region_loss_multi.py:74 calls on [0, 0, anchor_w, anchor_h] boxes (utils_multi.py:125-156); on the hot path
+    the anchor pick runs inside ssp_region_loss, this host version serves callers and tests."""
     if x1y1x2y2:
-        mx, Mx = min(box1[0], box2[0]), max(box1[2], box2[2])
-        my, My = min(box1[1], box2[1]), max(box1[3], box2[3])
-        w1, h1, w2, h2 = box1[2] - box1[0], box1[3] - box1[1], box2[2] - box2[0], box2[3] - box2[1]
+        ax0, ay0, ax1, ay1 = box1[0], box1[1], box1[2], box1[3]
+        bx0, by0, bx1, by1 = box2[0], box2[1], box2[2], box2[3]
     else:
-        mx = min(box1[0] - box1[2] / 2.0, box2[0] - box2[2] / 2.0)
-        Mx = max(box1[0] + box1[2] / 2.0, box2[0] + box2[2] / 2.0)
-        my = min(box1[1] - box1[3] / 2.0, box2[1] - box2[3] / 2.0)
-        My = max(box1[1] + box1[3] / 2.0, box2[1] + box2[3] / 2.0)
-        w1, h1, w2, h2 = box1[2], box1[3], box2[2], box2[3]
-    cw, ch = w1 + w2 - (Mx - mx), h1 + h2 - (My - my)
-    if cw <= 0 or ch <= 0:
+        ax0, ax1 = box1[0] - box1[2] / 2.0, box1[0] + box1[2] / 2.0
+        ay0, ay1 = box1[1] - box1[3] / 2.0, box1[1] + box1[3] / 2.0
+        bx0, bx1 = box2[0] - box2[2] / 2.0, box2[0] + box2[2] / 2.0
+        by0, by1 = box2[1] - box2[3] / 2.0, box2[1] + box2[3] / 2.0
+    ow, oh = _span(ax0, ax1, bx0, bx1), _span(ay0, ay1, by0, by1)
+    if ow <= 0 or oh <= 0:
         return 0.0
-    carea = cw * ch
-    return carea / (w1 * h1 + w2 * h2 - carea)
-
-
-def nms(boxes, nms_thresh):
-    if len(boxes) == 0:
-        return boxes
-    det_confs = torch.zeros(len(boxes))
-    for i in range(len(boxes)):
-        det_confs[i] = 1 - boxes[i][4]
-    _, order = torch.sort(det_confs)
-    out = []
-    for i in range(len(boxes)):
-        box_i = boxes[order[i]]
-        if box_i[4] > 0:
-            out.append(box_i)
-            for j in range(i + 1, len(boxes)):
-                box_j = boxes[order[j]]
-                if bbox_iou(box_i, box_j, x1y1x2y2=False) > nms_thresh:
-                    box_j[4] = 0
-    return out
+    inter = ow * oh
+    return inter / ((ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter)
 
 
 def region_rows(output, num_classes, num_keypoints, num_anchors):

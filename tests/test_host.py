@@ -231,7 +231,7 @@ sys.path.insert(0, os.path.join(r"%s", "dropin", "multi_obj_pose_estimation"))
 from darknet_multi import Darknet as DM      # train_multi.py
 from region_loss_multi import RegionLoss as RLM
 import utils_multi
-for n in "bbox_iou nms get_multi_region_boxes corner_confidences pnp get_3D_corners".split():
+for n in "bbox_iou get_multi_region_boxes corner_confidences pnp get_3D_corners".split():
     assert callable(getattr(utils_multi, n)), n
 print("ok")
 ''' % (os.path.join(root, 'cfg', 'yolo-pose.cfg'), os.path.join(root, 'cfg', 'yolo-pose.cfg'), root)
