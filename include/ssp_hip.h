@@ -102,8 +102,34 @@ int ssp_bn_act_bwd_partials(const float* x, int ldx, const float* g, int ldg, fl
                             const float* shift, const float* mean, const float* invstd, int C, int B, int H, int W,
                             float slope, int training, float* partial, int npartial, int zero_after, float* dgamma,
                             float* dbeta, float* c1, float* c2, void* stream);
+/* just the fp64 finalize of `npartial` rows of (sum dy, sum dy * xhat) pairs -> dgamma, dbeta, c1 = mean(dy),
+ * c2 = mean(dy * xhat) over npix pixels (c1 = c2 = 0 when training == 0) */
+int ssp_bn_bwd_finalize(float* partial, int npartial, int C, int64_t npix, int training, int zero_after, float* dgamma,
+                        float* dbeta, float* c1, float* c2, void* stream);
 /* out[c] = sum_p g[p][c]  (bias gradient of the linear head conv) */
 int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stream);
+
+/* ---- first block: conv 3x3 (image, Cin padded to 4 -> 32) + BatchNorm + leaky + 2x2/2 max-pool, training mode, with
+ * the convolution RECOMPUTED by every pass instead of stored (darknet.py:154-176 on the 416 x 416 input and its autograd
+ * backward; SURVEY.md section 7: the 22 MB-per-image map is the largest tensor of the net, its conv has K = 27).
+ * x: [B*H*W][4] (channel 3 zero), wt: ssp_repack_fwd(conv.weight, Cinp = 4) = [32][9][4]; H even, W % 16 == 0.
+ *   fwd_stats : stats[ssp_first_groups(B,H,W)][32][2] = per-group (mean, M2) of the raw conv output; feed
+ *               ssp_bn_fwd_finalize(stats, groups, ssp_first_tile_pixels(), B*H*W, 32, ...)
+ *   fwd_apply : out[pooled pixel][0..32) = maxpool2x2(leaky(scale * conv + shift))
+ *   bwd_reduce: partial[groups][32][2] = (sum dy, sum dy * xhat) from g = dL/d out (pool arg-max = first maximum in
+ *               window scan order, as ATen); feed ssp_bn_bwd_finalize
+ *   bwd_wgrad : dw[32][9][4] += filter gradient (dx formed in registers from g, the recomputed conv and c1 / c2)  */
+int ssp_first_tile_pixels(void);
+int ssp_first_groups(int B, int H, int W);
+int ssp_first_fwd_stats(const float* x, const float* wt, float* stats, int B, int H, int W, void* stream);
+int ssp_first_fwd_apply(const float* x, const float* wt, const float* scale, const float* shift, float slope, float* out,
+                        int ldo, int B, int H, int W, void* stream);
+int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float slope, float* partial, int B, int H, int W,
+                         void* stream);
+int ssp_first_bwd_wgrad(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* c1, const float* c2, float slope, float* dw,
+                        int B, int H, int W, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------ */
 /* One torch.optim.SGD step (train.py:388,106) over a contiguous fp32 range of n values, in place:

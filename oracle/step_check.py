@@ -86,6 +86,9 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     # the product's raw conv outputs, NHWC [M][coutp] -> NCHW CPU (backward rewrites them in place: fetch now)
     raws = {}
     for ind, cs in plan.convs.items():
+        if getattr(cs, 'first_live', False):
+            continue        # first block, fused form: its raw conv output is recomputed, never stored - the oracle
+                            # decides that block's pool winners / leaky signs on its own convolution of the same input
         r = cs.raw.view(B, cs.H, cs.W, cs.ldraw)[..., :cs.cout].permute(0, 3, 1, 2)
         raws[ind] = r.contiguous().cpu()
     loss = crit(out, tgt, epoch)

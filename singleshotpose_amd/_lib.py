@@ -39,6 +39,13 @@ _SIGS = {
     "ssp_bn_act_fwd": [P, I, P, I, P, P, I, I, I, I, I, F, P],
     "ssp_bn_bwd_blocks": [],
     "ssp_bn_act_bwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, I, F, I, P, P, P, P, P, P],
+    "ssp_bn_bwd_finalize": [P, I, I, L, I, I, P, P, P, P, P],
+    "ssp_first_tile_pixels": [],
+    "ssp_first_groups": [I, I, I],
+    "ssp_first_fwd_stats": [P, P, P, I, I, I, P],
+    "ssp_first_fwd_apply": [P, P, P, P, F, P, I, I, I, I, P],
+    "ssp_first_bwd_reduce": [P, P, P, I, P, P, P, P, F, P, I, I, I, P],
+    "ssp_first_bwd_wgrad": [P, P, P, I, P, P, P, P, P, P, F, P, I, I, I, P],
     "ssp_colsum": [P, I, L, I, P, P],
     "ssp_pose_errors": [P, I, P, P, P, I, I, P, P],
     "ssp_pts_diameter": [P, I, P, P, P],

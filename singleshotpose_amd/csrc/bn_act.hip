@@ -461,6 +461,17 @@ int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int 
   return SSP_OK;
 }
 
+int ssp_bn_bwd_finalize_launch(float* partial, int npartial, int C, int64_t npix, int training, int zero_after,
+                               float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream) {
+  SSP_CHECK_ARG(C % 4 == 0 && partial != nullptr && npartial > 0 && npix > 0 && (((uintptr_t)partial) & 15) == 0,
+                "bn_bwd_finalize: C %% 4 == 0, aligned partial rows");
+  SspProfScope prof(SSP_PROF_BN_ACT, stream, 0.0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ssp_cdiv(C, 4)), dim3(256), 0, stream, partial, npartial, C,
+                     1.0 / (double)npix, training, zero_after, dgamma, dbeta, c1, c2);
+  SSP_CHECK_LAUNCH("bn_bwd_finalize");
+  return SSP_OK;
+}
+
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream) {
   SSP_CHECK_ARG(C > 0 && M > 0, "colsum: bad sizes");
   SspProfScope prof(SSP_PROF_BN_ACT, stream, 0.0);

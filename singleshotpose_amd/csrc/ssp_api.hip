@@ -33,6 +33,19 @@ int ssp_bn_act_bwd_partials_launch(const float* x, int ldx, const float* g, int 
                                    int C, int B, int H, int W, float slope, int training, float* partial,
                                    int npartial, int zero_after, float* dgamma, float* dbeta, float* c1, float* c2,
                                    hipStream_t stream);
+int ssp_bn_bwd_finalize_launch(float* partial, int npartial, int C, int64_t npix, int training, int zero_after,
+                               float* dgamma, float* dbeta, float* c1, float* c2, hipStream_t stream);
+int ssp_first_tile_pixels_impl(void);
+int ssp_first_groups_impl(int B, int H, int W);
+int ssp_first_fwd_stats_launch(const float* x, const float* wt, float* stats, int B, int H, int W, hipStream_t stream);
+int ssp_first_fwd_apply_launch(const float* x, const float* wt, const float* scale, const float* shift, float slope,
+                               float* out, int ldo, int B, int H, int W, hipStream_t stream);
+int ssp_first_bwd_reduce_launch(const float* x, const float* wt, const float* g, int ldg, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, float slope, float* partial,
+                                int B, int H, int W, hipStream_t stream);
+int ssp_first_bwd_wgrad_launch(const float* x, const float* wt, const float* g, int ldg, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* c1,
+                               const float* c2, float slope, float* dw, int B, int H, int W, hipStream_t stream);
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
 int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float dampening,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
@@ -198,6 +211,33 @@ int ssp_bn_act_bwd_partials(const float* x, int ldx, const float* g, int ldg, fl
                             float* dbeta, float* c1, float* c2, void* stream) {
   return ssp_bn_act_bwd_partials_launch(x, ldx, g, ldg, dx, lddx, scale, shift, mean, invstd, C, B, H, W, slope, training,
                                         partial, npartial, zero_after, dgamma, dbeta, c1, c2, (hipStream_t)stream);
+}
+
+int ssp_bn_bwd_finalize(float* partial, int npartial, int C, int64_t npix, int training, int zero_after, float* dgamma,
+                        float* dbeta, float* c1, float* c2, void* stream) {
+  return ssp_bn_bwd_finalize_launch(partial, npartial, C, npix, training, zero_after, dgamma, dbeta, c1, c2,
+                                    (hipStream_t)stream);
+}
+int ssp_first_tile_pixels(void) { return ssp_first_tile_pixels_impl(); }
+int ssp_first_groups(int B, int H, int W) { return ssp_first_groups_impl(B, H, W); }
+int ssp_first_fwd_stats(const float* x, const float* wt, float* stats, int B, int H, int W, void* stream) {
+  return ssp_first_fwd_stats_launch(x, wt, stats, B, H, W, (hipStream_t)stream);
+}
+int ssp_first_fwd_apply(const float* x, const float* wt, const float* scale, const float* shift, float slope, float* out,
+                        int ldo, int B, int H, int W, void* stream) {
+  return ssp_first_fwd_apply_launch(x, wt, scale, shift, slope, out, ldo, B, H, W, (hipStream_t)stream);
+}
+int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float slope, float* partial, int B, int H, int W,
+                         void* stream) {
+  return ssp_first_bwd_reduce_launch(x, wt, g, ldg, scale, shift, mean, invstd, slope, partial, B, H, W,
+                                     (hipStream_t)stream);
+}
+int ssp_first_bwd_wgrad(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* c1, const float* c2, float slope, float* dw,
+                        int B, int H, int W, void* stream) {
+  return ssp_first_bwd_wgrad_launch(x, wt, g, ldg, scale, shift, mean, invstd, c1, c2, slope, dw, B, H, W,
+                                    (hipStream_t)stream);
 }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,

@@ -246,8 +246,22 @@ class Plan(object):
             cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
+            # First block in training mode: conv + BN + leaky + pool with the convolution recomputed by every pass
+            # instead of stored (csrc/conv_first.hip): the 32-channel full-resolution map (1.42 GB at batch 64, the
+            # largest tensor of the net, written and re-read five times by the generic path) never exists.
+            cs.first_fused = bool(cs.first and cs.bn and cs.pool and cs.k == 3 and cs.cinp == 4 and cs.cout == 32 and
+                                  cs.H % 2 == 0 and cs.W % 16 == 0 and M * 16 < (1 << 31) and
+                                  (M // 4) * cs.out.ld * 4 < (1 << 31) and device.type == 'cuda' and
+                                  os.environ.get('SSP_FIRST_FUSED', '1') != '0')
+            cs.first_live = False        # the last forward took the fused path (its backward must as well)
+            nstat = cs.ntile * cs.cout * 2
+            if cs.first_fused:
+                cs.first_groups = _lib.query('ssp_first_groups', B, cs.H, cs.W)
+                cs.first_tile = _lib.query('ssp_first_tile_pixels')
+                nstat = max(nstat, cs.first_groups * 64)
+                cs.first_partial = torch.empty(cs.first_groups * 64, **f32)
             if cs.bn:
-                cs.stats = torch.empty(cs.ntile * cs.cout * 2, **f32)
+                cs.stats = torch.empty(nstat, **f32)
         # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
         self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
@@ -576,6 +590,18 @@ class Plan(object):
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
                         self.bnversion[cs.ind] = None if inline_repack else bkey
                 wptr = cs.conv.weight.data_ptr() if cs.packed else self._wbuf(cs).data_ptr()
+                cs.first_live = False
+                if cs.first_fused and training and not cs.packed:
+                    bn = cs.bnm
+                    call('ssp_first_fwd_stats', cs.inp.ptr, wptr, cs.stats.data_ptr(), B, cs.H, cs.W, st)
+                    call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.first_groups, cs.first_tile, cs.M, cs.cout,
+                         bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                         bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
+                         v[2].data_ptr(), v[3].data_ptr(), st)
+                    call('ssp_first_fwd_apply', cs.inp.ptr, wptr, v[2].data_ptr(), v[3].data_ptr(), cs.slope,
+                         cs.out.ptr, cs.out.ld, B, cs.H, cs.W, st)
+                    cs.first_live = True
+                    continue
                 if not training and not need_grad and cs.needs_act and not cs.pool and cs.coutp == cs.cout:
                     # inference, un-pooled block: BatchNorm affine + leaky folded into the conv epilogue - one launch,
                     # no raw-output round trip (backward needs the raw output, so training / autograd keep two steps)
@@ -734,6 +760,26 @@ class Plan(object):
                     continue
                 g = self.grads[oind]
                 v = cs.vec
+                if cs.first_live:
+                    # first block, fused form: both backward passes recompute the convolution from the input
+                    dgam, dbet = gview(cs.bnm.weight), gview(cs.bnm.bias)
+                    out_grads[id(cs.bnm.weight)], out_grads[id(cs.bnm.bias)] = dgam, dbet
+                    wptr = self._wbuf(cs).data_ptr()
+                    call('ssp_first_bwd_reduce', cs.inp.ptr, wptr, g.ptr, g.ld, v[2].data_ptr(), v[3].data_ptr(),
+                         v[0].data_ptr(), v[1].data_ptr(), cs.slope, cs.first_partial.data_ptr(), B, cs.H, cs.W, st)
+                    call('ssp_bn_bwd_finalize', cs.first_partial.data_ptr(), cs.first_groups, cs.cout, cs.M,
+                         1 if training else 0, 0, dgam.data_ptr(), dbet.data_ptr(), v[4].data_ptr(), v[5].data_ptr(), st)
+                    side.wait_stream(main)
+                    gw = gview(cs.conv.weight, False)
+                    call('ssp_first_bwd_wgrad', cs.inp.ptr, wptr, g.ptr, g.ld, v[2].data_ptr(), v[3].data_ptr(),
+                         v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(), v[5].data_ptr(), cs.slope,
+                         self._gbuf(cs).data_ptr(), B, cs.H, cs.W, st2)
+                    call('ssp_unpack_grad', self._gbuf(cs).data_ptr(), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
+                    out_grads[id(cs.conv.weight)] = gw
+                    if self.reducer is not None:
+                        with torch.cuda.stream(side):
+                            self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
+                    continue
                 if cs.needs_act:
                     if cs.bn and cs.coutp == cs.cout:
                         dgam, dbet = gview(cs.bnm.weight), gview(cs.bnm.bias)
