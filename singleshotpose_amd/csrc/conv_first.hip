@@ -96,8 +96,10 @@ __device__ __forceinline__ f32x16 first_conv(const u32x2 (&xa)[9], const float (
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, xa[t][0]), wreg[2 * t], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, xa[t][1]), wreg[2 * t + 1], acc, 0, 0, 0);
+    // scalar copies first: __builtin_bit_cast on an ext-vector element mis-selects the element with this compiler
+    const unsigned u0 = xa[t][0], u1 = xa[t][1];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u0), wreg[2 * t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u1), wreg[2 * t + 1], acc, 0, 0, 0);
   }
   return acc;
 }

@@ -83,7 +83,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             asm volatile("" : "+s"(so));
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r]), rs, voff, so, 0);
+            // (copy to a scalar first: __builtin_bit_cast applied directly to an ext-vector ELEMENT picked element 0 for
+            // every r with this compiler - the first version of this path stored acc[i][j][0] sixteen times)
+            const float v = acc[i][j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, so, 0);
             so += ((r & 3) == 3) ? 5 * ld4 : ld4;
           }
         }
