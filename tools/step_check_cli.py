@@ -36,6 +36,7 @@ def main():
     print('STEPCHECK opt=%r env FIRST_FUSED=%s BN_FUSE=%s: %s' % (args.opt, os.environ.get('SSP_FIRST_FUSED', '1'),
                                                                     os.environ.get('SSP_BN_FUSE', '1'), summarize(res)))
     print('  worst grads:', [(k, float('%.3g' % v)) for k, v in worst])
+    print('  plans:', [(i, f, d) for i, f, d in res['plans'] if f or d])
     print('  fp64 fallbacks:', {k: {a: float('%.3g' % b) for a, b in v.items()} for k, v in res.get('grad_fp64_oracle', {}).items()})
 
 
