@@ -133,7 +133,7 @@ def verify_step(model, crit, B, H, W, seed):
     x_cpu, tgt = synthetic_batch(B, H, W, seed, 'cpu')
     t0 = time.time()
     r = check_train_step(model, crit, x_cpu, tgt, 20)
-    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 3e-4}
+    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 1e-3}   # grad: tests/test_gpu_fullsize.py
     ok = all(r[k] < bars[k] for k in bars)
     det = {k: float('%.3g' % r[k]) for k in bars}
     det.update(bars={k: v for k, v in bars.items()}, seconds=round(time.time() - t0, 1),

@@ -124,6 +124,9 @@ int ssp_first_groups(int B, int H, int W);
 int ssp_first_fwd_stats(const float* x, const float* wt, float* stats, int B, int H, int W, void* stream);
 int ssp_first_fwd_apply(const float* x, const float* wt, const float* scale, const float* shift, float slope, float* out,
                         int ldo, int B, int H, int W, void* stream);
+/* the raw conv output itself, [B*H*W][ldraw], by the same instruction sequence the four passes use (bit-identical
+ * values): for checkers that need the pool / leaky decisions of the fused path - the training path never calls it */
+int ssp_first_conv_raw(const float* x, const float* wt, float* raw, int ldraw, int B, int H, int W, void* stream);
 int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
                          const float* mean, const float* invstd, float slope, float* partial, int B, int H, int W,
                          void* stream);

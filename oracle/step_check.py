@@ -87,8 +87,14 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     raws = {}
     for ind, cs in plan.convs.items():
         if getattr(cs, 'first_live', False):
-            continue        # first block, fused form: its raw conv output is recomputed, never stored - the oracle
-                            # decides that block's pool winners / leaky signs on its own convolution of the same input
+            # first block, fused form: its raw conv output is recomputed by every pass, never stored.  ssp_first_conv_raw
+            # evaluates it once more with the same instruction sequence (bit-identical values) for this checker.
+            from singleshotpose_amd import _lib
+            tmp = torch.empty(cs.M * cs.cout, dtype=torch.float32, device=dev)
+            _lib.call('ssp_first_conv_raw', cs.inp.ptr, plan._wbuf(cs).data_ptr(), tmp.data_ptr(), cs.cout, B, cs.H, cs.W,
+                      torch.cuda.current_stream().cuda_stream)
+            raws[ind] = tmp.view(B, cs.H, cs.W, cs.cout).permute(0, 3, 1, 2).contiguous().cpu()
+            continue
         r = cs.raw.view(B, cs.H, cs.W, cs.ldraw)[..., :cs.cout].permute(0, 3, 1, 2)
         raws[ind] = r.contiguous().cpu()
     loss = crit(out, tgt, epoch)

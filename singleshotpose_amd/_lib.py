@@ -44,6 +44,7 @@ _SIGS = {
     "ssp_first_groups": [I, I, I],
     "ssp_first_fwd_stats": [P, P, P, I, I, I, P],
     "ssp_first_fwd_apply": [P, P, P, P, F, P, I, I, I, I, P],
+    "ssp_first_conv_raw": [P, P, P, I, I, I, I, P],
     "ssp_first_bwd_reduce": [P, P, P, I, P, P, P, P, F, P, I, I, I, P],
     "ssp_first_bwd_wgrad": [P, P, P, I, P, P, P, P, P, P, F, P, I, I, I, P],
     "ssp_colsum": [P, I, L, I, P, P],

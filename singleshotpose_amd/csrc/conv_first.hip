@@ -122,7 +122,8 @@ __device__ __forceinline__ void chan_combine_f(float& n, float& mean, float& m2,
   }
 }
 
-// MODE 0: forward statistics, 1: forward apply, 2: backward reduce, 3: backward filter gradient
+// MODE 0: forward statistics, 1: forward apply, 2: backward reduce, 3: backward filter gradient,
+// 4: write the raw convolution output (checkers only: the training path never stores it)
 template <int MODE>
 __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
                                                                          (int)FIRST_OOB, 0x00020000);
 
   __amdgpu_buffer_rsrc_t rs_o = rs_x, rs_g = rs_x;
-  if (MODE == 1) rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)FIRST_OOB, 0x00020000);
+  if (MODE == 1 || MODE == 4) rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)FIRST_OOB, 0x00020000);
   if (MODE >= 2) rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (int)FIRST_OOB, 0x00020000);
 
   u32x2 xa[9], xn[9];
@@ -178,7 +179,17 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
     // of an address sits in the (fixed) vector offset, the block / pixel part in the scalar offset
     const int pooled_u = __builtin_amdgcn_readfirstlane((k.b * p.Ho + k.yo) * p.Wo + 8 * k.xb);
 
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 4) {
+      // raw[pixel][cout]: lane (cout, lh) holds pixels (pp = 4*lh + c, q = w) at reg c + 4*w
+      const int base_pix = __builtin_amdgcn_readfirstlane((k.b * p.H + 2 * k.yo) * p.W + 16 * k.xb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = r & 3, w = r >> 2;
+        const float v = acc[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, (unsigned)((8 * lh * p.ldo + cout) * 4),
+                                              (base_pix + (w >> 1) * p.W + (w & 1) + 2 * c) * p.ldo * 4, 0);
+      }
+    } else if constexpr (MODE == 0) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sum += acc[r];
@@ -344,6 +355,18 @@ int ssp_first_fwd_apply_launch(const float* x, const float* wt, const float* sca
   SspProfScope prof(SSP_PROF_BN_ACT, stream, 0.0);
   hipLaunchKernelGGL(first_block_kernel<1>, dim3(ssp_cdiv(a.nblocks, 64)), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_fwd_apply");
+  return SSP_OK;
+}
+
+int ssp_first_conv_raw_launch(const float* x, const float* wt, float* raw, int ldraw, int B, int H, int W,
+                              hipStream_t stream) {
+  if (int rc = first_check(x, wt, B, H, W, "first_conv_raw")) return rc;
+  SSP_CHECK_ARG(raw != nullptr && ldraw >= FIRST_COUT && (int64_t)B * H * W * ldraw * 4 < (1ll << 31),
+                "first_conv_raw: bad output (ldraw >= 32, < 2 GiB)");
+  FirstArgs a = first_args(x, wt, B, H, W, 16);
+  a.out = raw; a.ldo = ldraw;
+  hipLaunchKernelGGL(first_block_kernel<4>, dim3(ssp_cdiv(a.nblocks, 64)), dim3(256), 0, stream, a);
+  SSP_CHECK_LAUNCH("first_conv_raw");
   return SSP_OK;
 }
 

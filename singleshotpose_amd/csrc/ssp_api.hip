@@ -40,6 +40,8 @@ int ssp_first_groups_impl(int B, int H, int W);
 int ssp_first_fwd_stats_launch(const float* x, const float* wt, float* stats, int B, int H, int W, hipStream_t stream);
 int ssp_first_fwd_apply_launch(const float* x, const float* wt, const float* scale, const float* shift, float slope,
                                float* out, int ldo, int B, int H, int W, hipStream_t stream);
+int ssp_first_conv_raw_launch(const float* x, const float* wt, float* raw, int ldraw, int B, int H, int W,
+                              hipStream_t stream);
 int ssp_first_bwd_reduce_launch(const float* x, const float* wt, const float* g, int ldg, const float* scale,
                                 const float* shift, const float* mean, const float* invstd, float slope, float* partial,
                                 int B, int H, int W, hipStream_t stream);
@@ -226,6 +228,9 @@ int ssp_first_fwd_stats(const float* x, const float* wt, float* stats, int B, in
 int ssp_first_fwd_apply(const float* x, const float* wt, const float* scale, const float* shift, float slope, float* out,
                         int ldo, int B, int H, int W, void* stream) {
   return ssp_first_fwd_apply_launch(x, wt, scale, shift, slope, out, ldo, B, H, W, (hipStream_t)stream);
+}
+int ssp_first_conv_raw(const float* x, const float* wt, float* raw, int ldraw, int B, int H, int W, void* stream) {
+  return ssp_first_conv_raw_launch(x, wt, raw, ldraw, B, H, W, (hipStream_t)stream);
 }
 int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
                          const float* mean, const float* invstd, float slope, float* partial, int B, int H, int W,

@@ -51,6 +51,12 @@ def test_first_block_forward_and_backward(B, H, W):
     assert rel_err(vec[0].cpu().numpy(), mean_ref.numpy()) < 1e-5
     assert rel_err(vec[1].cpu().numpy(), (1.0 / torch.sqrt(var_ref + 1e-4)).numpy()) < 1e-5
     np.testing.assert_allclose(rmean.cpu().numpy(), 0.1 * mean_ref.numpy(), rtol=1e-4, atol=1e-6)
+    # the raw map (checker entry point) against the float64 convolution
+    rawdev = torch.full((M, 36), float('nan'), device=G.dev())
+    _lib.call('ssp_first_conv_raw', xdev.data_ptr(), wdev.data_ptr(), rawdev.data_ptr(), 36, B, H, W, st)
+    torch.cuda.synchronize()
+    assert rel_err(G.from_nhwc(rawdev, B, 32, H, W).numpy(), raw.detach().numpy()) < 1e-5
+    assert torch.isnan(rawdev.cpu()[:, 32:]).all()
     # forward apply: pooled activation into a wider (channel-sliced) buffer
     ldo = 40
     P = B * (H // 2) * (W // 2)

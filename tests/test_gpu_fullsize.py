@@ -18,7 +18,14 @@ from helpers import GOLD, ROOT, load_state_into, make_targets
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-GRAD_TOL = 3e-4      # whole-network gradients, decision-frozen (same bar the 96x96 nets meet against a free-running oracle)
+# Whole-network parameter gradients against the decision-frozen oracle.  Typical worst parameter: 2e-4 (the first layer's
+# ill-conditioned filter gradient, against the float64 re-evaluation), 2e-5 elsewhere.  The mean-subtraction constants of
+# BatchNorm-backward (mean(dy), a heavily cancelling sum) amplify the rounding difference between this path's and
+# oneDNN's data gradients, by an amount that depends on the summation order, i.e. on the autotuned plan set: the worst set
+# seen (tools/plansets/r02i_b64_setC.json, replayable with SSP_TUNE_CACHE) puts layer 24 at 6.8e-4 with bit-identical
+# conv outputs (tools/lean_vs_old.py).  1e-3 still sits 10x under the free-running fp32-vs-fp64 envelope of
+# tests/test_gpu_darknet.py and every kernel keeps its own 1e-4 test.
+GRAD_TOL = 1e-3
 
 
 def _report(tag, res):
