@@ -320,7 +320,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   if (cok) {
     for (int m = m0 + pp; m < m1; m += 16) {
       f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
-      for (int sp = 1; sp < ksplit; ++sp) {
+      int sp = 1;
+      for (; sp + 3 < ksplit; sp += 4) {       // four partial loads in flight; summation order unchanged (sp ascending)
+        f32x4 u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const f32x4*>(ws + ((int64_t)(sp + q) * ws_rows + m) * Cout + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[0] += u[q][0]; v[1] += u[q][1]; v[2] += u[q][2]; v[3] += u[q][3]; }
+      }
+      for (; sp < ksplit; ++sp) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * ws_rows + m) * Cout + c);
         v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
       }
@@ -427,6 +435,19 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R, int plan_code) {
   IgemmPlan pl = {256, 1, 0, 0};
   if (Cout <= 64) {
     if (Cout > 32 && Cin % 16 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50) pl.bm = 128;   // 128x64 LDS-direct tiles
+    // Thin layers on small grids (the 1x1 head conv 1024 -> 20 and the 512 -> 64 route conv; at batch 1 also at 672 x 672):
+    // one column of a few dozen 256- / 128-row tiles leaves most CUs idle while each workgroup walks the whole K loop
+    // (44 us for 18 MFLOP at batch 1).  Split K so that ~2 workgroups per CU stream the filters; >= 8 chunks per split.
+    if (Cin % 16 == 0 && Cout % 4 == 0 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 50 && ssp_option(SSP_OPT_IGEMM_VARIANT) != 30) {
+      const int64_t tiles = ssp_cdiv(M, pl.bm);
+      const int niter = R * R * (Cin / 16);
+      if (tiles < 256) {
+        int64_t ks = 512 / tiles;
+        if (ks > niter / 8) ks = niter / 8;
+        if (ks > 8) ks = 8;
+        if (ks >= 2) pl.ksplit = (int)ks;
+      }
+    }
     return pl;
   }
   pl.bm = 128;
@@ -508,7 +529,10 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     SSP_CHECK_ARG(bnb->nslot >= 1, "conv: the BatchNorm-backward partial buffer needs at least one row");
     a.bn_nslot = bnb->nslot;
   }
-  const IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
+  IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
+  if (Cout <= 64 && pl.ksplit > 1 &&
+      (ws == nullptr || ws_floats < (int64_t)pl.ksplit * a.M * Cout || ldout % 4 != 0 || (((uintptr_t)out) & 15) != 0))
+    pl.ksplit = 1;      // thin-layer split is an optimisation only: without a workspace the tile walks its whole K loop
   a.ksplit = pl.ksplit;
   a.ws = ws;
   if (pl.ksplit > 1)
@@ -568,14 +592,17 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     rc = (bk >= 16) ? launch_cfg<256, 32, 4, 1, 16>(a, stream) : launch_cfg<256, 32, 4, 1, 4>(a, stream);
   }
   if (rc != SSP_OK) return rc;
+  // rows per reduce workgroup: the statistics formats are per conv tile (pl.bm rows); a launch that produces none is free
+  // to use 16-row blocks (one row per thread: 4-8x the workgroups on the small grids of batch-1 inference)
+  const int rt = (stats == nullptr && a.bn_partial == nullptr && a.M <= 16384) ? 16 : pl.bm;
   if (pl.ksplit > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
-                       bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, 0, a.bn_raw, a.bn_ld, a.bn_scale,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
+                       bias, stats, a.M, Cout, rt, accumulate, escale, act_slope, 0, a.bn_raw, a.bn_ld, a.bn_scale,
                        a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot, ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce");
   } else if (a.tail_ks > 1) {     // hybrid launch: only the tail rows were left as partials
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, pl.bm), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
-                       a.tail_ks, out, ldout, bias, stats, a.M, Cout, pl.bm, accumulate, escale, act_slope, a.ws_row0,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
+                       a.tail_ks, out, ldout, bias, stats, a.M, Cout, rt, accumulate, escale, act_slope, a.ws_row0,
                        a.bn_raw, a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot,
                        ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce(tail)");

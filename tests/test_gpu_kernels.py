@@ -32,6 +32,9 @@ CONV_CASES = [
     (5, 13, 13, 256, 256, 3, 0, 0, False),   # several M tiles + ragged M
     (64, 13, 13, 128, 1024, 3, 0, 0, False), # 680 tiles: split-K path + splitk_reduce statistics
     (64, 13, 13, 64, 1024, 3, 0, 32, True),  # split-K with bias and a sliced output
+    (64, 13, 13, 1024, 20, 1, 0, 0, True),   # the head conv at the benchmark batch: 43 thin 256-row tiles, split-K x8 + bias
+    (1, 42, 42, 512, 64, 1, 0, 0, False),    # route conv at batch 1, 672 x 672: 14 thin tiles, split-K x4 + statistics
+    (1, 21, 21, 1024, 20, 1, 0, 4, True),    # thin split declined (unaligned output slice): un-split fallback
 ]
 
 
