@@ -458,7 +458,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R, int plan_code) {
   if (forced > 0) {
     const int ftail = forced / 100000, fbm = (forced / 100) % 1000, fks = (forced / 10) % 10, fsl = forced % 10;
     const int niter16 = (Cin % 16 == 0) ? R * R * (Cin / 16) : 0;
-    const bool ok = (fbm == 64 || fbm == 128) && fks >= 1 && (fsl == 3 || fsl == 4) &&
+    const bool ok = (fbm == 64 || fbm == 128) && fks >= 1 && (fsl == 3 || fsl == 4 || fsl == 8) &&
                     (fks == 1 || (niter16 / fks >= 8 && Cout % 4 == 0)) && Cin % 16 == 0 &&
                     (ftail == 0 || (ftail >= 2 && ftail <= 9 && fks == 1 && Cout % 4 == 0 && niter16 / ftail >= 8));
     if (ok) { pl.bm = fbm; pl.ksplit = fks; pl.slots = fsl; pl.tail = ftail; return pl; }

@@ -22,14 +22,34 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define SSP_OOB 0x80000000u   // >= num_records of the descriptors below: the load returns zeros
 
+// s_waitcnt vmcnt(N) with a compile-time N (the immediate must be a literal in the asm string)
+template <int N>
+__device__ __forceinline__ void ssp_wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 25) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+  else static_assert(N == 10, "add the literal for this count");
+#endif
+}
+
 // PASS (0 = forward, 1 = data gradient) does not change the code: it gives the two uses distinct kernel names, so a
 // profile can tell the forward launches (exclusive on the GPU) from the dgrad launches (which overlap wgrad on a
 // second stream in Plan.backward).
 //
 // WM x WN = arrangement of the 4 waves over the tile: 2 x 2 for the square tiles, 4 x 1 for the 256 x 32 tile that
 // serves GEMMs with 32 output columns (the data gradient of layer 2: 64 -> 32 channels at 208 x 208).
+//
+// NSLOT = LDS ring depth.  3 and 4 are the throughput forms (2-3 workgroups per CU cover each other's memory latency).
+// 8 is the LATENCY form for grids too small to give a CU more than one workgroup (batch-1 inference at 672 x 672: 100-450
+// tiles): every workgroup walks K in step, so each chunk is a first touch served at fabric / HBM latency (~1-2 us), and
+// with one workgroup per CU nothing else hides it.  A chunk has to land only when its slot is about to be read, so the
+// per-step wait leaves NSLOT-3 chunks outstanding: 7 chunks run ahead of the MFMAs instead of 3 (the 4-slot ring's
+// wait - everything but the newest chunk - is the NSLOT = 4 case of the same rule).
 template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
-__global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) conv_igemm_dma_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN < 256) ? 3 : 2)) conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
   constexpr int BK = 16, NT = 256;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -215,7 +235,8 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   // ---- prologue: the first NSLOT-1 chunks in flight, wait for all, publish ----
 #pragma unroll
   for (int c = 0; c < NSLOT - 1; ++c) issue_loads(c * SLOTB);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (NSLOT >= 6) ssp_wait_vmcnt<(NSLOT - 3) * LPW>();      // chunks 0 and 1 are in; the rest keeps flying
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // fragment registers: with 4 slots the q = 0 fragments ping-pong between two sets (step parity) so that the NEXT
   // chunk's first fragments are fetched at the top of a step, a full chunk of MFMAs before they are needed.  With 3
@@ -228,17 +249,21 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   auto step = [&](auto slot_tag) {
     constexpr int S = decltype(slot_tag)::value;
     constexpr int S1 = (S + 1) % NSLOT, SL = (S + NSLOT - 1) % NSLOT;
-    constexpr int P = (NSLOT == 4) ? (S & 1) : 0;
+    constexpr int P = (NSLOT != 3) ? (S & 1) : 0;
     issue_loads(SL * SLOTB);                 // chunk it+NSLOT-1 (slot last read one barrier ago)
     read_frag(S * SLOTB, 1, fa1, fb1);
-    if constexpr (NSLOT == 4) read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // published by the previous barrier
+    if constexpr (NSLOT != 3) read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // published by the previous barrier
     __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads up here (the scheduler would sink them to their use)
     mma(fa0[P], fb0[P]);
     mma(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);       // ... and the wait + barrier below the MFMAs (MFMAs are register-only, so
                                              // the scheduler is otherwise free to hoist the barrier above them)
     // the chunk issued one step ago must have landed before it is published; this step's LPW loads stay in flight
-    if constexpr (LPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    if constexpr (NSLOT >= 6) {
+      // deep ring: only chunk it+2 (read at the top of the next step) has to be in; NSLOT-3 chunks stay in flight
+      ssp_wait_vmcnt<(NSLOT - 3) * LPW>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (LPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (LPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
@@ -246,7 +271,18 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
     if constexpr (NSLOT == 3) read_frag(S1 * SLOTB, 0, fa0[0], fb0[0]);
   };
   int it = 0;
-  if constexpr (NSLOT == 4) {
+  if constexpr (NSLOT == 8) {
+    for (; it + 8 <= niter; it += 8) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+    }
+  } else if constexpr (NSLOT == 4) {
     for (; it + 4 <= niter; it += 4) {
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
@@ -262,8 +298,14 @@ __global__ void __launch_bounds__(256, (NSLOT == 3 || BM + BN < 256) ? 3 : 2) co
   }
   if (it < niter) { step(std::integral_constant<int, 0>{}); ++it; }
   if (it < niter) { step(std::integral_constant<int, 1>{}); ++it; }
-  if constexpr (NSLOT == 4) {
+  if constexpr (NSLOT == 4 || NSLOT == 8) {
     if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
+  }
+  if constexpr (NSLOT == 8) {
+    if (it < niter) { step(std::integral_constant<int, 3>{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 4>{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 5>{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 6>{}); ++it; }
   }
 
   // retire the run-ahead DMA before the LDS is reused by the epilogue
@@ -326,6 +368,10 @@ int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int i
   if (slots == 3) three = true;
   if (slots == 4) three = false;
   const int tk = tail_ks;
+  if (slots == 8 && a.Cout > 64) {      // latency form (explicit plans only): 8-slot ring, one workgroup per CU
+    if (is_dgrad) return bm == 64 ? launch_dma<64, 128, 1, 8>(a, tk, stream) : launch_dma<128, 128, 1, 8>(a, tk, stream);
+    return bm == 64 ? launch_dma<64, 128, 0, 8>(a, tk, stream) : launch_dma<128, 128, 0, 8>(a, tk, stream);
+  }
   if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, 0, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, 0, stream);
   if (is_dgrad) {
     if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, tk, stream) : launch_dma<128, 64, 1>(a, tk, stream);

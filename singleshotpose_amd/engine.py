@@ -392,6 +392,9 @@ class Plan(object):
         # the last partial wave split 3 / 2 ways over K)
         cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814,
                  12823, 6423, 6424, 206414, 212813, 406413, 406414, 412813)
+        # ring depth 8 = the latency form of the kernel (one workgroup per CU, 7 chunks in flight): only worth timing on
+        # grids that cannot give a CU several workgroups anyway (small-batch inference)
+        lat = (6418, 12818, 6428, 12828, 6438)
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
             return
@@ -412,9 +415,9 @@ class Plan(object):
             best, best_t = 0, None
             # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
             # deep K splits put every CU on the weight stream
-            deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4)) \
+            deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4, 8)) \
                 if mn <= (1 << 21) else ()
-            for code in cands + deep:
+            for code in cands + (lat if mn <= (1 << 23) else ()) + deep:
                 if ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
                 try:

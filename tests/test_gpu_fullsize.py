@@ -111,7 +111,7 @@ def test_tuned_plans_every_candidate_matches_default_on_bench_shapes():
     up to fp32 summation order."""
     from gpu_util import dev, stream
     from singleshotpose_amd import _lib
-    cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814)
+    cands = (12813, 12814, 6414, 6413, 12824, 12834, 306413, 306414, 312813, 312814, 206413, 212814, 6418, 12818, 6438, 306418)
     g = torch.Generator(device='cuda').manual_seed(3)
     for (B, H, W, Cin, Cout, R) in ((64, 13, 13, 1024, 1024, 3), (64, 26, 26, 256, 512, 3)):
         M = B * H * W
