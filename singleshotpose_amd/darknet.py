@@ -188,7 +188,6 @@ class Darknet(nn.Module):
         if plan is None:
             while len(self._plans) >= self._max_plans:
                 self._plans.popitem(last=False)
-            before = torch.cuda.memory_allocated(device)
             while True:
                 try:
                     plan = Plan(self, shape[0], shape[1], shape[2], device)
@@ -198,9 +197,10 @@ class Darknet(nn.Module):
                         raise
                     self._plans.popitem(last=False)
                     torch.cuda.empty_cache()
-                    before = torch.cuda.memory_allocated(device)
             # forward buffers now, gradient buffers of about the same size on the first backward
-            plan.nbytes_est = 2 * max(0, torch.cuda.memory_allocated(device) - before)
+            # (counted from the plan's own tensors: an allocator delta is wrong whenever the garbage collector frees another
+            # model's buffers while the plan is being built)
+            plan.nbytes_est = 2 * plan.footprint()
             budget = self._plan_mem_frac * torch.cuda.get_device_properties(device).total_memory
             while self._plans and plan.nbytes_est + sum(p.nbytes_est for p in self._plans.values()) > budget:
                 self._plans.popitem(last=False)

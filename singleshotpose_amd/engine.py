@@ -294,6 +294,18 @@ class Plan(object):
         self._graph = self._graph_key = self._x_static = self._y_static = None
         self._graph_failed = False
 
+    def footprint(self):
+        """Bytes of device memory this plan's forward buffers hold (each storage counted once)."""
+        seen, total = set(), 0
+        ts = [self.x_nhwc, self.ws, self.bn_partial] + [a.t for a in self.acts if a is not None]
+        for cs in self.convs.values():
+            ts += [cs.raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None)]
+        for t in ts:
+            if t is not None and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+        return total
+
     # ------------------------------------------------------------------ lazily allocated filter staging
     def _wbuf(self, cs):
         if getattr(cs, 'wbuf', None) is None:
