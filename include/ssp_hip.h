@@ -33,10 +33,13 @@ int ssp_set_option(const char* name, int value);
  * stats (nullable): [ceil(B*H*W / ssp_conv_stats_tile_m(...))][Cout][2] per-tile (mean, M2) of the raw output,
  * input of ssp_bn_fwd_finalize (training-mode BatchNorm statistics, darknet.py:157).
  * workspace: ssp_conv_workspace_floats(...) floats (0 for most shapes; the 13x13 layers split their K loop over
- * several workgroups per tile and sum the partial tiles from it).  The shape arguments of the two queries are those
+ * several workgroups per tile and sum the partial tiles from it; so do thin layers - Cout <= 64 - whose single tile
+ * column cannot fill the chip, e.g. the 1024 -> 20 head conv: those fall back to the un-split walk when no workspace
+ * is passed).  The shape arguments of the two queries are those
  * of the launch (for ssp_conv_dgrad: Cin = channels of dy, Cout = channels of dx).
  * plan: tile / split choice of THIS launch, 0 = the library's shape heuristic, else
- *   tail*100000 + tile_rows*100 + ksplit*10 + ring_slots   (tile_rows 64|128, ksplit 1..9, ring_slots 3|4,
+ *   tail*100000 + tile_rows*100 + ksplit*10 + ring_slots   (tile_rows 64|128, ksplit 1..9, ring_slots 3|4, or 8 =
+ *   the latency form for grids of about one workgroup per CU: seven K chunks in flight, one workgroup per CU;
  *   tail 0 or 2..9 = hybrid launch: whole resident waves un-split, the last partial wave's tiles split `tail` ways);
  * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
  * models) may run different plans concurrently.  The same code must be passed to the two queries. */
