@@ -17,6 +17,12 @@ returns the error of every quantity the step produces:
             gradient whose fp32 oracle value is itself inexact (ill-conditioned sum) is compared against the float64
             re-evaluation of the oracle's own operands instead ('grad_fp64_oracle' lists those and all three errors)
   grad_out  error of dL/d(head) (the RegionLoss gradient) against the oracle's on the product's head
+  grad64 / grad64_ref (exact=True)  the same raw-output-frozen network once more in FLOAT64 (its BatchNorm arithmetic,
+            and therefore the leaky signs / pool winners of elements within fp32 rounding of a decision boundary, are
+            float64's own) and against it the worst per-parameter distance of the product ('grad64') and of the fp32
+            oracle itself ('grad64_ref').  A yardstick, not a tighter oracle: it shows how far fp32 arithmetic of ANY
+            summation order sits from float64 on this network (1e-3 .. 1e-2 on some parameters) and that the product
+            sits exactly where the reference does, parameter by parameter ('grad64_by_param' holds the pairs)
 
 SURVEY.md section 8(d) config 2 / config 5; tolerance north_star: fp32 conv / loss within 1e-4 relative.
 """
@@ -70,7 +76,7 @@ def _clone(state, requires_grad=False):
     return out
 
 
-def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_backward=True):
+def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_backward=True, exact=False):
     """model: product Darknet on the GPU (train mode is set here); crit: product RegionLoss(Multi); x_cpu (B,3,H,W)
     float32 CPU; tgt (B, 50*21) CPU labels.  Returns a dict of errors (see the module docstring) plus 'plans', the
     (layer, forward plan code, dgrad plan code) triples that were active."""
@@ -160,9 +166,47 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             gerr['%d.bias' % ind] = _rel(seq[0].bias.grad.cpu(), e['bias'].grad)
     res['grad_by_param'] = gerr
     res['grad'] = max(gerr.values())
+    if exact:
+        res.update(exact_frozen_errors(model, state0, st_b, x_cpu, raws, r_frz['grad']))
     return res
 
 
+def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head):
+    """Float64 evaluation of the raw-output-frozen network (same overrides: the product's raw conv outputs, exactly
+    representable in float64; batch statistics - and with them the leaky sign / pool winner of the few elements that sit
+    within fp32 rounding of a decision boundary - are float64's) and, against it, the per-parameter distances of the
+    product's gradients and of the fp32 oracle's (st32 after its backward)."""
+    st64 = []
+    for e in state0:
+        if e is None:
+            st64.append(None)
+            continue
+        d = {}
+        for k, v in e.items():
+            d[k] = v.double().clone()
+            if not k.startswith('running'):
+                d[k].requires_grad_(True)
+        st64.append(d)
+    y64 = forward_ref(model.blocks, st64, x_cpu.double(), training=True,
+                      raw_override={k: v.double() for k, v in raws.items()})
+    y64.backward(grad_head.double())
+    pairs = {}
+    for ind, e in enumerate(st64):
+        if e is None:
+            continue
+        seq = model.models[ind]
+        names = [('weight', seq[0].weight)]
+        if 'bn_weight' in e:
+            names += [('bn_weight', seq[1].weight), ('bn_bias', seq[1].bias)]
+        else:
+            names += [('bias', seq[0].bias)]
+        for k, prm in names:
+            g64 = e[k].grad
+            pairs['%d.%s' % (ind, k)] = (_rel(prm.grad.cpu(), g64), _rel(st32[ind][k].grad, g64))
+    return {'grad64_by_param': pairs, 'grad64': max(a for a, _ in pairs.values()),
+            'grad64_ref': max(b for _, b in pairs.values())}
+
+
 def summarize(res):
-    keys = [k for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad') if k in res]
+    keys = [k for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad', 'grad64', 'grad64_ref') if k in res]
     return ', '.join('%s %.2e' % (k, res[k]) for k in keys)

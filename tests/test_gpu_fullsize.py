@@ -24,7 +24,8 @@ TOL = 1e-4
 # oneDNN's data gradients, by an amount that depends on the summation order, i.e. on the autotuned plan set: the worst set
 # seen (tools/plansets/r02i_b64_setC.json, replayable with SSP_TUNE_CACHE) puts layer 24 at 6.8e-4 with bit-identical
 # conv outputs (tools/lean_vs_old.py).  1e-3 still sits 10x under the free-running fp32-vs-fp64 envelope of
-# tests/test_gpu_darknet.py and every kernel keeps its own 1e-4 test.
+# tests/test_gpu_darknet.py and every kernel keeps its own 1e-4 test.  _assert_exact below adds a yardstick: measured
+# against a float64 evaluation of the same frozen network the product is exactly as far away as the fp32 oracle, parameter by parameter.
 GRAD_TOL = 1e-3
 
 
@@ -44,6 +45,19 @@ def _assert_step(res):
     assert res['grad'] < GRAD_TOL, sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:5]
 
 
+def _assert_exact(res):
+    """Against the FLOAT64 evaluation of the raw-output-frozen network (oracle/step_check.py: float64 re-decides the few
+    leaky / pool elements that sit within fp32 rounding of a boundary, so it is a yardstick, not an exact value): every
+    parameter gradient of the product is either within 1e-4 of it or no further from it than 3x the fp32 oracle
+    (PyTorch-CPU / oneDNN) is.  Measured: the two distances agree to 3 digits on the worst parameters (5.709e-4 vs
+    5.714e-4 on layer 8 at B = 64) - the HIP path sits where the reference's own arithmetic sits."""
+    worst = sorted(res['grad64_by_param'].items(), key=lambda kv: -kv[1][0])[:4]
+    print('vs float64 frozen backward: product %.2e, fp32 oracle %.2e | worst (product, oracle) %s' % (
+        res['grad64'], res['grad64_ref'], worst))
+    for name, (mine, ref) in res['grad64_by_param'].items():
+        assert mine <= max(TOL, 3.0 * ref), (name, mine, ref)
+
+
 def test_headline_config_b64_train_step_with_tuned_plans():
     """Exactly what bench.py times: torch.manual_seed(0) default-initialised cfg/yolo-pose.cfg, batch 64 of synthetic
     416 x 416 images with one label each (bench.synthetic_batch, seed 1000), epoch 20, autotuner on."""
@@ -58,11 +72,12 @@ def test_headline_config_b64_train_step_with_tuned_plans():
     model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).cuda()
     x, tgt = synthetic_batch(64, 416, 416, 1000, 'cpu')
     n_rej = len(engine.TUNE_REJECTED)
-    res = check_train_step(model, RegionLoss(), x, tgt, 20)
+    res = check_train_step(model, RegionLoss(), x, tgt, 20, exact=True)
     _report('yolo-pose B=64 416', res)
     assert any(f or d for _, f, d in res['plans']), "the autotuner picked no plan: nothing tuned was exercised"
     assert len(engine.TUNE_REJECTED) == n_rej, engine.TUNE_REJECTED[n_rej:]
     _assert_step(res)
+    _assert_exact(res)
 
 
 def test_headline_config_b8_seeded_weights_pretrain_epoch():
@@ -99,10 +114,11 @@ def test_multi_object_full_trunk_train_step():
     tgt = torch.from_numpy(make_targets(rs, B, [1, 2, 3, 4, 5, 6, 7, 8], multi=True))
     crit = RegionLossMulti(num_keypoints=9, num_classes=13, anchors=model.anchors, num_anchors=5, pretrain_num_epochs=0)
     kw = dict(num_classes=13, num_anchors=5, anchors=model.anchors, pretrain_num_epochs=0, multi=True)
-    res = check_train_step(model, crit, x, tgt, 1, loss_kwargs=kw)
+    res = check_train_step(model, crit, x, tgt, 1, loss_kwargs=kw, exact=True)
     _report('yolo-pose-multi B=8 416', res)
     assert tuple(model._plans.keys())[0][:3] == (B, 416, 416)
     _assert_step(res)
+    _assert_exact(res)
 
 
 def test_tuned_plans_every_candidate_matches_default_on_bench_shapes():
