@@ -151,6 +151,33 @@ int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, i
 /* uint8 (B,H,W,C) image bytes -> fp32 [B*H*W][ld], value/255 as transforms.ToTensor (dataset.py:113-131); channels
  * [C,Cpad) = 0.  SURVEY.md section 8(f) row 3: the byte image is uploaded instead of the fp32 NCHW tensor. */
 int ssp_u8hwc_to_nhwc(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cpad, int ld, void* stream);
+/* ---- training-time augmentation (second half): image.py:14-31,46-76,111-128 ----------
+ * What the reference does per sample with Pillow on the host - bg.resize + mask composite, jitter crop (zero fill) +
+ * resize to the network shape, HSV jitter through Image.point tables - as batched launches, byte-exact with Pillow.
+ * A resize is two passes (horizontal over the rows the vertical pass needs, 8-bit intermediate, then vertical) of a
+ * per-output-index FIR with Pillow's 22-bit fixed-point bicubic coefficients; the coefficient rows come from the caller
+ * (singleshotpose_amd/image.py computes them in double, as ImagingResample's precompute_coeffs does).
+ * One descriptor per sample, an array of them in DEVICE memory; u8 images are (rows, cols, 3) with a byte pitch. */
+typedef struct SspResampleDesc {
+  const void* src;     /* pass 0: source image (src_h x src_w); pass 1: the horizontal pass's output (src_h rows) */
+  void* dst;           /* dst_h x dst_w */
+  const void* bounds;  /* int32 [n_out][2] = (first input index, taps) of this pass's axis */
+  const void* kk;      /* int32 [n_out][ksize] fixed-point coefficients */
+  const void* img;     /* epilogue 1: foreground image, dst-sized */
+  const void* mask;    /* epilogue 1: mask, dst-sized: channel value >= 128 keeps the foreground (image.py:121-125) */
+  const void* lut;     /* epilogue 2: 768 bytes = H, S, V tables of image.py:14-31 */
+  int src_w, src_h, src_pitch;
+  int x0, y0;          /* pass 0: logical input pixel (Y, X) is source pixel (Y + y0, X + x0); outside the source = 0 (crop) */
+  int row0;            /* first logical input row the vertical pass needs (pass 0 writes rows row0 ...; pass 1 reads them) */
+  int dst_w, dst_h, dst_pitch;
+  int ksize, img_pitch, reserved;
+} SspResampleDesc;
+/* pass 0 = horizontal (epilogue must be 0), 1 = vertical; epilogue 0 = store, 1 = composite with img / mask,
+ * 2 = distort_image (RGB -> HSV -> tables -> RGB).  max_dst_pixels = the largest dst_w * dst_h of the batch. */
+int ssp_resample_u8(const SspResampleDesc* descs_dev, int count, int pass, int epilogue, int max_dst_pixels, void* stream);
+/* distort_image alone on npix packed RGB pixels (mode 0, lut = 768 bytes); modes 1 / 2 = RGB -> HSV / HSV -> RGB only
+ * (Image.convert), which is how the tests pin both conversions over all 2^24 inputs. */
+int ssp_distort_u8(const unsigned char* rgb, unsigned char* out, int64_t npix, const unsigned char* lut, int mode, void* stream);
 /* conv.weight (Cout,Cin,R,R) (cfg.py:157,175) -> [Cout][R*R][Cinp] */
 int ssp_repack_fwd(const float* w, float* out, int Cout, int Cin, int Cinp, int R, void* stream);
 /* conv.weight -> [Cin][R*R][Coutp], taps flipped */

@@ -54,6 +54,8 @@ _SIGS = {
     "ssp_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "ssp_nhwc_to_nchw": [P, P, I, I, I, I, I, P],
     "ssp_u8hwc_to_nhwc": [P, P, I, I, I, I, I, I, P],
+    "ssp_resample_u8": [P, I, I, I, I, P],
+    "ssp_distort_u8": [P, P, L, P, I, P],
     "ssp_repack_fwd": [P, P, I, I, I, I, P],
     "ssp_repack_dgrad": [P, P, I, I, I, I, P],
     "ssp_repack_dgrad_packed": [P, P, I, I, I, I, P],

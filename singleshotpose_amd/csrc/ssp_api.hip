@@ -56,6 +56,8 @@ int ssp_nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int H, i
 int ssp_pose_errors_launch(const double* verts, int N, const double* Rt_gt, const double* Rt_pr, const double* K,
                            int k_per_pose, int n, double* out, hipStream_t stream);
 int ssp_pts_diameter_launch(const double* pts, int N, double* out, double* scratch, hipStream_t stream);
+int ssp_resample_u8_launch(const SspResampleDesc* descs, int count, int pass, int epilogue, int max_dst_pixels, hipStream_t stream);
+int ssp_distort_u8_launch(const unsigned char* rgb, unsigned char* out, int64_t npix, const unsigned char* lut, int mode, hipStream_t stream);
 int ssp_u8hwc_to_nhwc_launch(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cp, int ld,
                              hipStream_t stream);
 int ssp_repack_fwd_launch(const float* w, float* out, int Cout, int Cin, int Cinp, int R, hipStream_t stream);
@@ -288,6 +290,12 @@ int ssp_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, i
 }
 int ssp_u8hwc_to_nhwc(const unsigned char* src, float* dst, int B, int H, int W, int C, int Cpad, int ld, void* stream) {
   return ssp_u8hwc_to_nhwc_launch(src, dst, B, H, W, C, Cpad, ld, (hipStream_t)stream);
+}
+int ssp_resample_u8(const SspResampleDesc* descs_dev, int count, int pass, int epilogue, int max_dst_pixels, void* stream) {
+  return ssp_resample_u8_launch(descs_dev, count, pass, epilogue, max_dst_pixels, (hipStream_t)stream);
+}
+int ssp_distort_u8(const unsigned char* rgb, unsigned char* out, int64_t npix, const unsigned char* lut, int mode, void* stream) {
+  return ssp_distort_u8_launch(rgb, out, npix, lut, mode, (hipStream_t)stream);
 }
 int ssp_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int ld, void* stream) {
   return ssp_nhwc_to_nchw_launch(src, dst, B, C, H, W, ld, (hipStream_t)stream);

@@ -1,0 +1,355 @@
+"""Training-time image augmentation on the MI355X: the reference's image.py, batched and byte-exact with Pillow.
+
+/root/reference/image.py runs, per sample and on the host, change_background (:111-128), data_augmentation (:46-76) and
+distort_image (:14-31) through Pillow, then dataset.py:113-131 turns the PIL image into a float tensor.  Here the decoded
+bytes of a whole batch go to the GPU once and four launches produce the augmented uint8 batch (csrc/image_aug.hip),
+which Darknet.forward takes as it is (ssp_u8hwc_to_nhwc does ToTensor's /255): SURVEY.md section 8(f) row 3.
+
+    aug = DeviceAugmenter(device)
+    batch_u8, labels = aug.load_data_detection_batch(imgs, masks, bgs, label_rows, shape=(416, 416), jitter=0.2, hue=0.1,
+                                                     saturation=1.5, exposure=1.5, num_keypoints=9, max_num_gt=50)
+    out = model(batch_u8)                 # (B, H, W, 3) uint8 on the GPU; labels: (B, 50 * 21) float64 as dataset.py yields
+
+What stays on the host: file decoding (PIL / libjpeg, out of scope), the random draws (Python's `random`, in the reference's
+order, so a seeded run draws what the reference draws), the label arithmetic (fill_truth_detection, 21 numbers per
+object) and the resampling coefficient tables - Pillow computes those in double per output column / row
+(ImagingResample.precompute_coeffs); resample_coeffs() restates that with the same operation order, vectorised over the
+batch (a few hundred KB per batch, one upload together with the launch descriptors).
+No CPU fallback: without the HIP library this module raises.
+"""
+import ctypes
+import math
+import random as _random
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PRECISION_BITS = 32 - 8 - 2      # Pillow: 8-bit pixels, 2 guard bits
+
+
+class _Desc(ctypes.Structure):      # include/ssp_hip.h: SspResampleDesc
+    _fields_ = [('src', ctypes.c_uint64), ('dst', ctypes.c_uint64), ('bounds', ctypes.c_uint64), ('kk', ctypes.c_uint64),
+                ('img', ctypes.c_uint64), ('mask', ctypes.c_uint64), ('lut', ctypes.c_uint64),
+                ('src_w', ctypes.c_int), ('src_h', ctypes.c_int), ('src_pitch', ctypes.c_int),
+                ('x0', ctypes.c_int), ('y0', ctypes.c_int), ('row0', ctypes.c_int),
+                ('dst_w', ctypes.c_int), ('dst_h', ctypes.c_int), ('dst_pitch', ctypes.c_int),
+                ('ksize', ctypes.c_int), ('img_pitch', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+
+_DESC_DTYPE = np.dtype([(n, np.uint64 if t is ctypes.c_uint64 else np.int32) for n, t in _Desc._fields_])
+assert _DESC_DTYPE.itemsize == ctypes.sizeof(_Desc) == 104
+
+
+def resample_coeffs(in_sizes, out_size):
+    """Pillow's bicubic coefficient rows (precompute_coeffs + normalize_coeffs_8bpc over the whole input range) for a batch
+    of input sizes and one output size.  Returns (ksize, bounds int32 (B, out, 2), kk int32 (B, out, ksize)); rows are
+    padded with zeros to the largest ksize of the batch.  Every operation is an IEEE double operation in the order the C
+    code performs it, so the integer coefficients are Pillow's."""
+    in_sizes = np.asarray(in_sizes, dtype=np.int64).reshape(-1)
+    scale = in_sizes.astype(np.float64) / float(out_size)
+    filterscale = np.maximum(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int((np.ceil(support).astype(np.int64) * 2 + 1).max())
+    ss = 1.0 / filterscale
+    xx = np.arange(out_size, dtype=np.float64)
+    center = (xx[None, :] + 0.5) * scale[:, None]
+    xmin = np.trunc(center - support[:, None] + 0.5).astype(np.int64)
+    xmin = np.maximum(xmin, 0)
+    xmax = np.trunc(center + support[:, None] + 0.5).astype(np.int64)
+    xmax = np.minimum(xmax, in_sizes[:, None])
+    n = xmax - xmin
+    x = np.arange(ksize, dtype=np.int64)[None, None, :]
+    arg = ((x + xmin[..., None]).astype(np.float64) - center[..., None] + 0.5) * ss[:, None, None]
+    arg = np.abs(arg)
+    a = -0.5
+    near = ((a + 2.0) * arg - (a + 3.0)) * arg * arg + 1
+    far = (((arg - 5) * arg + 8) * arg - 4) * a
+    w = np.where(arg < 1.0, near, np.where(arg < 2.0, far, 0.0))
+    w = np.where(x < n[..., None], w, 0.0)
+    ww = np.zeros(n.shape, np.float64)
+    for j in range(ksize):                       # the C loop's summation order
+        ww = ww + w[..., j]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        k = np.where(ww[..., None] != 0.0, w / ww[..., None], w)
+    fixed = np.where(k < 0, np.trunc(-0.5 + k * (1 << PRECISION_BITS)), np.trunc(0.5 + k * (1 << PRECISION_BITS)))
+    kk = np.where(x < n[..., None], fixed, 0.0).astype(np.int32)
+    bounds = np.stack([xmin, n], -1).astype(np.int32)
+    return ksize, bounds, kk
+
+
+def _lut_entry(v):
+    # Image.point(callable) on an 8-bit band: Python floats are rounded (half to even) and clipped to 0..255
+    if isinstance(v, float):
+        v = round(v)
+    return min(255, max(0, int(v)))
+
+
+def distort_tables(hue, sat, val):
+    """The H, S and V tables of distort_image (image.py:14-31) as 768 bytes."""
+    def change_hue(x):
+        x += hue * 255
+        if x > 255:
+            x -= 255
+        if x < 0:
+            x += 255
+        return x
+    return np.array([_lut_entry(change_hue(i)) for i in range(256)] + [_lut_entry(i * sat) for i in range(256)] +
+                    [_lut_entry(i * val) for i in range(256)], np.uint8)
+
+
+def rand_scale(s, rng=_random):
+    """image.py:33-37."""
+    scale = rng.uniform(1, s)
+    if rng.randint(1, 10000) % 2:
+        return scale
+    return 1. / scale
+
+
+def draw_augmentation(ow, oh, jitter, hue, saturation, exposure, rng=_random):
+    """The random draws of data_augmentation / random_distort_image (image.py:46-64, :39-44), in the reference's order."""
+    dw, dh = int(ow * jitter), int(oh * jitter)
+    pleft = rng.randint(-dw, dw)
+    pright = rng.randint(-dw, dw)
+    ptop = rng.randint(-dh, dh)
+    pbot = rng.randint(-dh, dh)
+    flip = rng.randint(1, 10000) % 2
+    dhue = rng.uniform(-hue, hue)
+    dsat = rand_scale(saturation, rng)
+    dexp = rand_scale(exposure, rng)
+    return dict(pleft=pleft, pright=pright, ptop=ptop, pbot=pbot, flip=flip, dhue=dhue, dsat=dsat, dexp=dexp)
+
+
+def fill_truth_detection(labpath, w, h, flip, dx, dy, sx, sy, num_keypoints, max_num_gt):
+    """image.py:78-109 (same signature): label rows of one image moved into the crop.  `labpath` may also be the parsed
+    (n, 2K+3) array."""
+    num_labels = 2 * num_keypoints + 3
+    label = np.zeros((max_num_gt, num_labels))
+    if isinstance(labpath, str):
+        import os
+        if not os.path.getsize(labpath):
+            return np.reshape(label, (-1))
+        bs = np.loadtxt(labpath)
+    else:
+        bs = np.array(labpath, dtype=np.float64)
+    if bs is None or bs.size == 0:
+        return np.reshape(label, (-1))
+    bs = np.reshape(bs, (-1, num_labels))
+    cc = 0
+    for i in range(bs.shape[0]):
+        row = bs[i]
+        row[1] = min(0.999, max(0, row[1] * sx - dx))      # the centroid stays inside the image
+        row[2] = min(0.999, max(0, row[2] * sy - dy))
+        for j in range(1, num_keypoints):
+            row[2 * j + 1] = row[2 * j + 1] * sx - dx
+            row[2 * j + 2] = row[2 * j + 2] * sy - dy
+        label[cc] = row
+        cc += 1
+        if cc >= 50:
+            break
+    return np.reshape(label, (-1))
+
+
+class DeviceAugmenter(object):
+    """Batched image.py on one GPU.  Buffers (staging, intermediates) are cached and grow to the largest batch seen."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("singleshotpose_amd.image runs on the MI355X HIP kernels only (no CPU fallback)")
+        _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self._bufs = {}
+        self._events = {}
+
+    # -------------------------------------------------------------------------------------------- buffers
+    def _buf(self, name, nbytes, pinned=False):
+        t = self._bufs.get(name)
+        if pinned:      # the previous batch's asynchronous upload must have left this staging buffer
+            ev = self._events.get(name)
+            if ev is not None:
+                ev.synchronize()
+        if t is None or t.numel() < nbytes:
+            n = int(nbytes * 1.25) + 256
+            t = torch.empty(n, dtype=torch.uint8, pin_memory=True) if pinned else \
+                torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def _to_device_list(self, arrays, name):
+        """list of (h, w, 3) uint8 numpy arrays / CUDA tensors -> list of (device pointer, h, w): host arrays travel in one
+        pinned staging copy."""
+        out, host, off = [None] * len(arrays), [], 0
+        for i, a in enumerate(arrays):
+            if isinstance(a, torch.Tensor):
+                if not (a.is_cuda and a.dtype == torch.uint8 and a.dim() == 3 and a.size(2) == 3 and a.is_contiguous()):
+                    raise ValueError("image tensors must be contiguous (h, w, 3) uint8 on the GPU")
+                out[i] = (a.data_ptr(), a.size(0), a.size(1))
+                self._keep.append(a)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.uint8)
+                if a.ndim != 3 or a.shape[2] != 3:
+                    raise ValueError("images are (h, w, 3) uint8 RGB arrays (Image.open(...).convert('RGB'))")
+                host.append((i, a, off))
+                off += (a.size + 15) // 16 * 16
+        if host:
+            stage = self._buf(name + '_pin', off, pinned=True)
+            dev = self._buf(name + '_dev', off)
+            sv = stage.numpy()
+            for i, a, o in host:
+                sv[o:o + a.size] = a.reshape(-1)
+            dev[:off].copy_(stage[:off], non_blocking=True)
+            self._events[name + '_pin'] = torch.cuda.current_stream(self.device).record_event()
+            for i, a, o in host:
+                out[i] = (dev.data_ptr() + o, a.shape[0], a.shape[1])
+        return out
+
+    # -------------------------------------------------------------------------------------------- the pipeline
+    def load_data_detection_batch(self, imgs, masks, bgs, labels, shape, jitter, hue, saturation, exposure,
+                                  num_keypoints=9, max_num_gt=50, rng=_random, draws=None):
+        """load_data_detection (image.py:130-145) for a batch.
+
+        imgs / masks / bgs: per sample an (h, w, 3) uint8 RGB array (numpy, or an already resident CUDA tensor); image and
+        mask of a sample have the same size, backgrounds any size.  labels: per sample a label file path or the parsed
+        (n, 2K+3) rows.  shape = (width, height) of the network input.  The random numbers come from `rng` (default: the
+        global `random`, as in the reference) sample by sample in the reference's order; `draws` (list of
+        draw_augmentation dicts) overrides them.
+        Returns (uint8 CUDA tensor (B, height, width, 3), float64 CPU tensor (B, max_num_gt * (2K+3)))."""
+        B = len(imgs)
+        if not (B and len(masks) == B and len(bgs) == B and len(labels) == B):
+            raise ValueError("imgs, masks, bgs and labels must be non-empty lists of one length")
+        sw, sh = int(shape[0]), int(shape[1])
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._keep = []
+        with torch.cuda.device(self.device):
+            im = self._to_device_list(imgs, 'img')
+            mk = self._to_device_list(masks, 'mask')
+            bg = self._to_device_list(bgs, 'bg')
+            for i in range(B):
+                if im[i][1:] != mk[i][1:]:
+                    raise ValueError("image %d and its mask differ in size" % i)
+            oh = np.array([t[1] for t in im], np.int64)
+            ow = np.array([t[2] for t in im], np.int64)
+            bh = np.array([t[1] for t in bg], np.int64)
+            bw = np.array([t[2] for t in bg], np.int64)
+            if draws is None:
+                draws = [draw_augmentation(int(ow[i]), int(oh[i]), jitter, hue, saturation, exposure, rng) for i in range(B)]
+            pleft = np.array([d['pleft'] for d in draws], np.int64)
+            ptop = np.array([d['ptop'] for d in draws], np.int64)
+            swidth = ow - pleft - np.array([d['pright'] for d in draws], np.int64)
+            sheight = oh - ptop - np.array([d['pbot'] for d in draws], np.int64)
+            cw, ch = swidth - 1, sheight - 1           # img.crop((l, t, l + swidth - 1, t + sheight - 1)), image.py:64
+            if (cw <= 0).any() or (ch <= 0).any():
+                raise ValueError("jitter leaves an empty crop")
+
+            # ---- coefficient tables: background -> image size (per sample sizes), crop -> network shape ----
+            def per_sample(in_sizes, out_sizes):
+                """out sizes differ per sample (the background is resized to each image's size): group equal ones."""
+                res = [None] * B
+                for o in np.unique(out_sizes):
+                    idx = np.nonzero(out_sizes == o)[0]
+                    ks, bnd, kk = resample_coeffs(in_sizes[idx], int(o))
+                    for j, i in enumerate(idx):
+                        res[i] = (ks, bnd[j], kk[j])
+                return res
+            bg_h, bg_v = per_sample(bw, ow), per_sample(bh, oh)
+            ks_ch, bnd_ch, kk_ch = resample_coeffs(cw, sw)
+            ks_cv, bnd_cv, kk_cv = resample_coeffs(ch, sh)
+
+            # rows of each horizontal pass = what its vertical pass reads (ImagingResample: ybox_first .. ybox_last)
+            def rows(bnd):
+                return int(bnd[0, 0]), int(bnd[-1, 0] + bnd[-1, 1])
+            bg_rows = [rows(bg_v[i][1]) for i in range(B)]
+            cr_rows = [rows(bnd_cv[i]) for i in range(B)]
+
+            # ---- one blob: descriptors (4 launches x B), coefficient tables, distort tables ----
+            parts, off = [], [0]
+
+            def put(arr):
+                arr = np.ascontiguousarray(arr)
+                o = off[0]
+                parts.append((o, arr))
+                off[0] = (o + arr.nbytes + 15) // 16 * 16
+                return o
+            desc = np.zeros((4, B), _DESC_DTYPE)
+            o_desc = put(desc)
+            o_tab = {}
+            for i in range(B):
+                o_tab[i] = dict(bgh_b=put(bg_h[i][1]), bgh_k=put(bg_h[i][2]), bgv_b=put(bg_v[i][1]), bgv_k=put(bg_v[i][2]),
+                                ch_b=put(bnd_ch[i]), ch_k=put(kk_ch[i]), cv_b=put(bnd_cv[i]), cv_k=put(kk_cv[i]),
+                                lut=put(distort_tables(draws[i]['dhue'], draws[i]['dsat'], draws[i]['dexp'])))
+            blob_n = off[0]
+            # intermediates
+            t1_off = np.concatenate([[0], np.cumsum([(r[1] - r[0]) * int(ow[i]) * 3 for i, r in enumerate(bg_rows)])])
+            cp_off = np.concatenate([[0], np.cumsum(oh * ow * 3)])
+            t2_off = np.concatenate([[0], np.cumsum([(r[1] - r[0]) * sw * 3 for r in cr_rows])])
+            tmp1 = self._buf('tmp1', int(t1_off[-1]))
+            comp = self._buf('comp', int(cp_off[-1]))
+            tmp2 = self._buf('tmp2', int(t2_off[-1]))
+            out = torch.empty(B, sh, sw, 3, dtype=torch.uint8, device=self.device)
+            blob_dev = self._buf('blob_dev', blob_n)
+            base = blob_dev.data_ptr()
+            for i in range(B):
+                t = o_tab[i]
+                r0, r1 = bg_rows[i]
+                d = desc[0, i]      # background, horizontal pass: (bh x bw) -> rows [r0, r1) x ow
+                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = bg[i][0], bw[i], bh[i], bw[i] * 3
+                d['row0'] = r0
+                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = tmp1.data_ptr() + int(t1_off[i]), ow[i], r1 - r0, ow[i] * 3
+                d['bounds'], d['kk'], d['ksize'] = base + t['bgh_b'], base + t['bgh_k'], bg_h[i][0]
+                d = desc[1, i]      # background, vertical pass + composite (image.py:111-128)
+                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = tmp1.data_ptr() + int(t1_off[i]), ow[i], r1 - r0, ow[i] * 3
+                d['row0'] = r0
+                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = comp.data_ptr() + int(cp_off[i]), ow[i], oh[i], ow[i] * 3
+                d['bounds'], d['kk'], d['ksize'] = base + t['bgv_b'], base + t['bgv_k'], bg_v[i][0]
+                d['img'], d['mask'], d['img_pitch'] = im[i][0], mk[i][0], ow[i] * 3
+                r0, r1 = cr_rows[i]
+                d = desc[2, i]      # crop window of the composite, horizontal pass to the network width
+                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = comp.data_ptr() + int(cp_off[i]), ow[i], oh[i], ow[i] * 3
+                d['x0'], d['y0'], d['row0'] = pleft[i], ptop[i], r0
+                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = tmp2.data_ptr() + int(t2_off[i]), sw, r1 - r0, sw * 3
+                d['bounds'], d['kk'], d['ksize'] = base + t['ch_b'], base + t['ch_k'], ks_ch
+                d = desc[3, i]      # vertical pass to the network height + distort_image (image.py:14-31)
+                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = tmp2.data_ptr() + int(t2_off[i]), sw, r1 - r0, sw * 3
+                d['row0'] = r0
+                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = out.data_ptr() + i * sh * sw * 3, sw, sh, sw * 3
+                d['bounds'], d['kk'], d['ksize'] = base + t['cv_b'], base + t['cv_k'], ks_cv
+                d['lut'] = base + t['lut']
+            parts[0] = (o_desc, desc)
+            blob = self._buf('blob_pin', blob_n, pinned=True)
+            bv = blob.numpy()
+            for o, arr in parts:
+                bv[o:o + arr.nbytes] = arr.reshape(-1).view(np.uint8)
+            blob_dev[:blob_n].copy_(blob[:blob_n], non_blocking=True)
+            self._events['blob_pin'] = torch.cuda.current_stream(self.device).record_event()
+
+            dsz = _DESC_DTYPE.itemsize
+            mx = [int(max((bg_rows[i][1] - bg_rows[i][0]) * ow[i] for i in range(B))), int((oh * ow).max()),
+                  int(max((r[1] - r[0]) * sw for r in cr_rows)), sh * sw]
+            _lib.call('ssp_resample_u8', base + o_desc + 0 * B * dsz, B, 0, 0, mx[0], st)
+            _lib.call('ssp_resample_u8', base + o_desc + 1 * B * dsz, B, 1, 1, mx[1], st)
+            _lib.call('ssp_resample_u8', base + o_desc + 2 * B * dsz, B, 0, 0, mx[2], st)
+            _lib.call('ssp_resample_u8', base + o_desc + 3 * B * dsz, B, 1, 2, mx[3], st)
+
+        # ---- labels (host): image.py:139-144 ----
+        lab = np.zeros((B, max_num_gt * (2 * num_keypoints + 3)))
+        for i in range(B):
+            sx, sy = float(swidth[i]) / float(ow[i]), float(sheight[i]) / float(oh[i])
+            dx = (float(pleft[i]) / float(ow[i])) / sx
+            dy = (float(ptop[i]) / float(oh[i])) / sy
+            lab[i] = fill_truth_detection(labels[i], sw, sh, draws[i]['flip'], dx, dy, 1. / sx, 1. / sy, num_keypoints,
+                                          max_num_gt)
+        self._keep = []
+        return out, torch.from_numpy(lab)
+
+
+def distort_image(rgb_u8, hue, sat, val):
+    """distort_image (image.py:14-31) of a CUDA uint8 (..., 3) RGB tensor."""
+    if not (rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.size(-1) == 3):
+        raise RuntimeError("singleshotpose_amd.image.distort_image takes a CUDA uint8 (..., 3) tensor (no CPU fallback)")
+    x = rgb_u8.contiguous()
+    out = torch.empty_like(x)
+    lut = torch.from_numpy(distort_tables(hue, sat, val)).to(x.device)
+    _lib.call('ssp_distort_u8', x.data_ptr(), out.data_ptr(), x.numel() // 3, lut.data_ptr(), 0,
+              torch.cuda.current_stream(x.device).cuda_stream)
+    return out

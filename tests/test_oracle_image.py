@@ -83,3 +83,26 @@ def test_whole_chain_matches_the_reference_golden():
         assert np.array_equal(out, g[pre + 'out']), ci
         label = R.fill_truth_detection(g[pre + 'labels'], flip, dx, dy, 1. / sx, 1. / sy, 9, 50)
         assert np.array_equal(label, g[pre + 'label']), ci
+
+
+def test_product_host_tables_match_the_oracle():
+    """Host side of singleshotpose_amd/image.py (no GPU needed): the batched coefficient tables, the distort tables and
+    the random-draw order against the oracle restatement (which the tests above pin to Pillow and to the reference)."""
+    from singleshotpose_amd import image as P
+    for out in (416, 64, 37, 640, 5):
+        ins = [640, 480, 500, 375, 37, 29, 64, 13, 7, 3, 833, out]
+        ks, bnd, kk = P.resample_coeffs(ins, out)
+        for j, n in enumerate(ins):
+            k1, b1, c1 = R.resample_coeffs(n, out)
+            assert k1 <= ks and np.array_equal(bnd[j], b1), (n, out)
+            assert np.array_equal(kk[j][:, :k1], c1) and not kk[j][:, k1:].any(), (n, out)
+    for hue, sat, val in ((-0.1, 1.5, 0.7), (0.0999, 1 / 1.37, 1.21), (0.0, 1.0, 1.0)):
+        lh, ls, lv = R.distort_luts(hue, sat, val)
+        assert np.array_equal(P.distort_tables(hue, sat, val), np.concatenate([lh, ls, lv]))
+    a, b = random.Random(5), random.Random(5)
+    for _ in range(20):
+        assert P.draw_augmentation(640, 480, 0.2, 0.1, 1.5, 1.5, a) == R.draw_augmentation(b, 640, 480, 0.2, 0.1, 1.5, 1.5)
+    g = np.load(os.path.join(GOLD, 'image_aug.npz'))
+    rows = g['c1_labels']
+    assert np.array_equal(P.fill_truth_detection(rows, 96, 64, 0, 0.05, -0.02, 1.1, 0.9, 9, 50),
+                          R.fill_truth_detection(rows, 0, 0.05, -0.02, 1.1, 0.9, 9, 50))
