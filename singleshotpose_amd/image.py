@@ -18,7 +18,6 @@ batch (a few hundred KB per batch, one upload together with the launch descripto
 No CPU fallback: without the HIP library this module raises.
 """
 import ctypes
-import math
 import random as _random
 
 import numpy as np
@@ -79,24 +78,20 @@ def resample_coeffs(in_sizes, out_size):
     return ksize, bounds, kk
 
 
-def _lut_entry(v):
-    # Image.point(callable) on an 8-bit band: Python floats are rounded (half to even) and clipped to 0..255
-    if isinstance(v, float):
-        v = round(v)
-    return min(255, max(0, int(v)))
-
-
 def distort_tables(hue, sat, val):
-    """The H, S and V tables of distort_image (image.py:14-31) as 768 bytes."""
-    def change_hue(x):
-        x += hue * 255
-        if x > 255:
-            x -= 255
-        if x < 0:
-            x += 255
-        return x
-    return np.array([_lut_entry(change_hue(i)) for i in range(256)] + [_lut_entry(i * sat) for i in range(256)] +
-                    [_lut_entry(i * val) for i in range(256)], np.uint8)
+    """The H, S and V tables of distort_image (image.py:14-31): 768 bytes per sample ((B, 768) for array arguments).
+    Image.point(callable) on an 8-bit band evaluates the callable on 0..255 and rounds the Python floats half to even
+    (np.rint), clipped to 0..255; the hue table wraps once in each direction, in the reference's order."""
+    hue = np.atleast_1d(np.asarray(hue, np.float64))[:, None]
+    sat = np.atleast_1d(np.asarray(sat, np.float64))[:, None]
+    val = np.atleast_1d(np.asarray(val, np.float64))[:, None]
+    i = np.arange(256, dtype=np.float64)[None, :]
+    x = i + hue * 255
+    x = np.where(x > 255, x - 255, x)
+    x = np.where(x < 0, x + 255, x)
+    t = np.concatenate([x, i * sat, i * val], 1)
+    t = np.clip(np.rint(t), 0, 255).astype(np.uint8)
+    return t[0] if t.shape[0] == 1 else t
 
 
 def rand_scale(s, rng=_random):
@@ -161,6 +156,8 @@ class DeviceAugmenter(object):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._bufs = {}
         self._events = {}
+        self.time_kernels = False
+        self.kernel_events = None
 
     # -------------------------------------------------------------------------------------------- buffers
     def _buf(self, name, nbytes, pinned=False):
@@ -273,48 +270,55 @@ class DeviceAugmenter(object):
                 return o
             desc = np.zeros((4, B), _DESC_DTYPE)
             o_desc = put(desc)
-            o_tab = {}
-            for i in range(B):
-                o_tab[i] = dict(bgh_b=put(bg_h[i][1]), bgh_k=put(bg_h[i][2]), bgv_b=put(bg_v[i][1]), bgv_k=put(bg_v[i][2]),
-                                ch_b=put(bnd_ch[i]), ch_k=put(kk_ch[i]), cv_b=put(bnd_cv[i]), cv_k=put(kk_cv[i]),
-                                lut=put(distort_tables(draws[i]['dhue'], draws[i]['dsat'], draws[i]['dexp'])))
+            # tables shared by the whole batch go in as one array each, per-sample ones (background) one by one
+            o_ch_b, o_ch_k, o_cv_b, o_cv_k = put(bnd_ch), put(kk_ch), put(bnd_cv), put(kk_cv)
+            luts = distort_tables([d['dhue'] for d in draws], [d['dsat'] for d in draws], [d['dexp'] for d in draws])
+            o_lut = put(luts.reshape(B, 768))
+            o_bg = np.array([[put(bg_h[i][1]), put(bg_h[i][2]), put(bg_v[i][1]), put(bg_v[i][2])] for i in range(B)], np.int64)
             blob_n = off[0]
             # intermediates
-            t1_off = np.concatenate([[0], np.cumsum([(r[1] - r[0]) * int(ow[i]) * 3 for i, r in enumerate(bg_rows)])])
+            bg_r0 = np.array([r[0] for r in bg_rows], np.int64)
+            bg_nr = np.array([r[1] - r[0] for r in bg_rows], np.int64)
+            cr_r0 = np.array([r[0] for r in cr_rows], np.int64)
+            cr_nr = np.array([r[1] - r[0] for r in cr_rows], np.int64)
+            t1_off = np.concatenate([[0], np.cumsum(bg_nr * ow * 3)])
             cp_off = np.concatenate([[0], np.cumsum(oh * ow * 3)])
-            t2_off = np.concatenate([[0], np.cumsum([(r[1] - r[0]) * sw * 3 for r in cr_rows])])
+            t2_off = np.concatenate([[0], np.cumsum(cr_nr * sw * 3)])
             tmp1 = self._buf('tmp1', int(t1_off[-1]))
             comp = self._buf('comp', int(cp_off[-1]))
             tmp2 = self._buf('tmp2', int(t2_off[-1]))
             out = torch.empty(B, sh, sw, 3, dtype=torch.uint8, device=self.device)
             blob_dev = self._buf('blob_dev', blob_n)
             base = blob_dev.data_ptr()
-            for i in range(B):
-                t = o_tab[i]
-                r0, r1 = bg_rows[i]
-                d = desc[0, i]      # background, horizontal pass: (bh x bw) -> rows [r0, r1) x ow
-                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = bg[i][0], bw[i], bh[i], bw[i] * 3
-                d['row0'] = r0
-                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = tmp1.data_ptr() + int(t1_off[i]), ow[i], r1 - r0, ow[i] * 3
-                d['bounds'], d['kk'], d['ksize'] = base + t['bgh_b'], base + t['bgh_k'], bg_h[i][0]
-                d = desc[1, i]      # background, vertical pass + composite (image.py:111-128)
-                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = tmp1.data_ptr() + int(t1_off[i]), ow[i], r1 - r0, ow[i] * 3
-                d['row0'] = r0
-                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = comp.data_ptr() + int(cp_off[i]), ow[i], oh[i], ow[i] * 3
-                d['bounds'], d['kk'], d['ksize'] = base + t['bgv_b'], base + t['bgv_k'], bg_v[i][0]
-                d['img'], d['mask'], d['img_pitch'] = im[i][0], mk[i][0], ow[i] * 3
-                r0, r1 = cr_rows[i]
-                d = desc[2, i]      # crop window of the composite, horizontal pass to the network width
-                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = comp.data_ptr() + int(cp_off[i]), ow[i], oh[i], ow[i] * 3
-                d['x0'], d['y0'], d['row0'] = pleft[i], ptop[i], r0
-                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = tmp2.data_ptr() + int(t2_off[i]), sw, r1 - r0, sw * 3
-                d['bounds'], d['kk'], d['ksize'] = base + t['ch_b'], base + t['ch_k'], ks_ch
-                d = desc[3, i]      # vertical pass to the network height + distort_image (image.py:14-31)
-                d['src'], d['src_w'], d['src_h'], d['src_pitch'] = tmp2.data_ptr() + int(t2_off[i]), sw, r1 - r0, sw * 3
-                d['row0'] = r0
-                d['dst'], d['dst_w'], d['dst_h'], d['dst_pitch'] = out.data_ptr() + i * sh * sw * 3, sw, sh, sw * 3
-                d['bounds'], d['kk'], d['ksize'] = base + t['cv_b'], base + t['cv_k'], ks_cv
-                d['lut'] = base + t['lut']
+            idx = np.arange(B, dtype=np.int64)
+            p_im = np.array([t[0] for t in im], np.uint64)
+            p_mk = np.array([t[0] for t in mk], np.uint64)
+            p_bg = np.array([t[0] for t in bg], np.uint64)
+            p_t1 = (tmp1.data_ptr() + t1_off[:-1]).astype(np.uint64)
+            p_cp = (comp.data_ptr() + cp_off[:-1]).astype(np.uint64)
+            p_t2 = (tmp2.data_ptr() + t2_off[:-1]).astype(np.uint64)
+
+            def fill(d, **kw):
+                for k, v in kw.items():
+                    d[k] = v
+            # background, horizontal pass: (bh x bw) -> rows [r0, r1) x ow
+            fill(desc[0], src=p_bg, src_w=bw, src_h=bh, src_pitch=bw * 3, row0=bg_r0, dst=p_t1, dst_w=ow, dst_h=bg_nr,
+                 dst_pitch=ow * 3, bounds=(base + o_bg[:, 0]).astype(np.uint64), kk=(base + o_bg[:, 1]).astype(np.uint64),
+                 ksize=np.array([t[0] for t in bg_h]))
+            # background, vertical pass + composite (image.py:111-128)
+            fill(desc[1], src=p_t1, src_w=ow, src_h=bg_nr, src_pitch=ow * 3, row0=bg_r0, dst=p_cp, dst_w=ow, dst_h=oh,
+                 dst_pitch=ow * 3, bounds=(base + o_bg[:, 2]).astype(np.uint64), kk=(base + o_bg[:, 3]).astype(np.uint64),
+                 ksize=np.array([t[0] for t in bg_v]), img=p_im, mask=p_mk, img_pitch=ow * 3)
+            # crop window of the composite, horizontal pass to the network width
+            fill(desc[2], src=p_cp, src_w=ow, src_h=oh, src_pitch=ow * 3, x0=pleft, y0=ptop, row0=cr_r0, dst=p_t2, dst_w=sw,
+                 dst_h=cr_nr, dst_pitch=sw * 3, bounds=(base + o_ch_b + idx * bnd_ch[0].nbytes).astype(np.uint64),
+                 kk=(base + o_ch_k + idx * kk_ch[0].nbytes).astype(np.uint64), ksize=ks_ch)
+            # vertical pass to the network height + distort_image (image.py:14-31)
+            fill(desc[3], src=p_t2, src_w=sw, src_h=cr_nr, src_pitch=sw * 3, row0=cr_r0,
+                 dst=(out.data_ptr() + idx * (sh * sw * 3)).astype(np.uint64), dst_w=sw, dst_h=sh, dst_pitch=sw * 3,
+                 bounds=(base + o_cv_b + idx * bnd_cv[0].nbytes).astype(np.uint64),
+                 kk=(base + o_cv_k + idx * kk_cv[0].nbytes).astype(np.uint64), ksize=ks_cv,
+                 lut=(base + o_lut + idx * 768).astype(np.uint64))
             parts[0] = (o_desc, desc)
             blob = self._buf('blob_pin', blob_n, pinned=True)
             bv = blob.numpy()
@@ -324,12 +328,18 @@ class DeviceAugmenter(object):
             self._events['blob_pin'] = torch.cuda.current_stream(self.device).record_event()
 
             dsz = _DESC_DTYPE.itemsize
-            mx = [int(max((bg_rows[i][1] - bg_rows[i][0]) * ow[i] for i in range(B))), int((oh * ow).max()),
-                  int(max((r[1] - r[0]) * sw for r in cr_rows)), sh * sw]
+            mx = [int((bg_nr * ow).max()), int((oh * ow).max()), int(cr_nr.max()) * sw, sh * sw]
+            ev = None
+            if self.time_kernels:       # tools/aug_bench.py: device time of the four launches alone
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _lib.call('ssp_resample_u8', base + o_desc + 0 * B * dsz, B, 0, 0, mx[0], st)
             _lib.call('ssp_resample_u8', base + o_desc + 1 * B * dsz, B, 1, 1, mx[1], st)
             _lib.call('ssp_resample_u8', base + o_desc + 2 * B * dsz, B, 0, 0, mx[2], st)
             _lib.call('ssp_resample_u8', base + o_desc + 3 * B * dsz, B, 1, 2, mx[3], st)
+            if ev is not None:
+                ev[1].record()
+                self.kernel_events = ev
 
         # ---- labels (host): image.py:139-144 ----
         lab = np.zeros((B, max_num_gt * (2 * num_keypoints + 3)))
@@ -349,7 +359,7 @@ def distort_image(rgb_u8, hue, sat, val):
         raise RuntimeError("singleshotpose_amd.image.distort_image takes a CUDA uint8 (..., 3) tensor (no CPU fallback)")
     x = rgb_u8.contiguous()
     out = torch.empty_like(x)
-    lut = torch.from_numpy(distort_tables(hue, sat, val)).to(x.device)
+    lut = torch.from_numpy(distort_tables(hue, sat, val).reshape(-1)).to(x.device)
     _lib.call('ssp_distort_u8', x.data_ptr(), out.data_ptr(), x.numel() // 3, lut.data_ptr(), 0,
               torch.cuda.current_stream(x.device).cuda_stream)
     return out
