@@ -299,13 +299,19 @@ def main():
     ms, work, cnt = collect()
     # Per-family breakdown (kernel_ms_per_step, roofline_bwd): a separate, untimed pass of the same steps with every
     # launch bracketed by events.
+    # Collected step by step and reduced with the MEDIAN over steps: one stretched event (a clock ramp, another process
+    # on the host) would otherwise add milliseconds to a family's mean.
     nb = min(args.steps, 5)
-    _lib.call('ssp_prof_enable', -1)
+    per_step = []
     for _ in range(nb):
+        _lib.call('ssp_prof_enable', -1)
         loss = step()
-    barrier()
-    _lib.call('ssp_prof_enable', 0)
-    bms, bwork, bcnt = collect()
+        barrier()
+        _lib.call('ssp_prof_enable', 0)
+        per_step.append(collect())
+    bms = [float(np.median([p[0][k] for p in per_step])) * nb for k in range(nk)]
+    bwork = [float(np.median([p[1][k] for p in per_step])) * nb for k in range(nk)]
+    bcnt = [float(np.median([p[2][k] for p in per_step])) * nb for k in range(nk)]
     final_loss = float(loss)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
