@@ -133,8 +133,9 @@ def verify_step(model, crit, B, H, W, seed):
     x_cpu, tgt = synthetic_batch(B, H, W, seed, 'cpu')
     t0 = time.time()
     r = check_train_step(model, crit, x_cpu, tgt, 20, exact=True)
-    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 1e-3}   # grad: tests/test_gpu_fullsize.py
-    ok = all(r[k] < bars[k] for k in bars)
+    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 5e-4}   # grad: 1e-4 but for the
+    # first layer's ill-conditioned filter gradient (5e-4 against its float64 re-evaluation), tests/test_gpu_fullsize.py
+    ok = all(r[k] < bars[k] for k in bars) and all(e < 1e-4 for n, e in r['grad_by_param'].items() if n != '0.weight')
     # yardstick: distance to a float64 evaluation of the same raw-output-frozen network - the product's worst parameter
     # and the fp32 oracle's own (the product must be within 1e-4 or 3x the oracle's distance, parameter by parameter)
     ok = ok and all(a <= max(1e-4, 3.0 * b) for a, b in r['grad64_by_param'].values())

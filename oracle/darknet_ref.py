@@ -71,7 +71,8 @@ def reorg_ref(x, stride=2):
     return x.view(B, s * s * C, H // s, W // s)
 
 
-def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None, tape=None):
+def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None, tape=None,
+                act_override=None):
     """Runs the layer list on CPU tensors.  `state` entries may require grad; running stats are updated in place
     when training.  Returns the raw head (and every layer output when keep=True).
 
@@ -83,7 +84,14 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
     forward passes need (rounding flips max-pool / leaky decisions and the flips propagate).
     raws (dict, optional): filled with this function's own convolution outputs {layer index: tensor (detached)}.
     tape (dict, optional): filled with {layer index: (conv input, conv output node with retain_grad, padding)} so a
-    caller can re-evaluate a filter gradient in float64 after backward (step_check.py: ill-conditioned sums)."""
+    caller can re-evaluate a filter gradient in float64 after backward (step_check.py: ill-conditioned sums).
+    act_override {layer index: (B,Cout,H,W) tensor}: the product's leaky(BN(conv)) output of an un-pooled block.  Only its
+    SIGN is used: the leaky branch of every element is the one the product took (y > 0 there), while value and gradient
+    stay this function's own.  With frozen raw outputs the pre-activation y = BN(raw) still differs between two fp32
+    evaluations in its last bits (scale * raw + shift against (raw - mean) * invstd * gamma + beta), so an element
+    within ~1e-7 of zero can take different branches; when that element carries a large share of the gradient (the
+    label's cell in the deep layers) one flipped branch moves a channel's gradient by 1e-3.  Both branches are valid
+    fp32 results - freezing the decision removes the ambiguity from the comparison."""
     outputs = {}
     for ind, b in enumerate(blocks[1:]):
         t = b['type']
@@ -104,7 +112,10 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
                 x = F.batch_norm(x, e['running_mean'], e['running_var'], e['bn_weight'], e['bn_bias'], training,
                                  momentum, 1e-4)
             if b['activation'] == 'leaky':
-                x = F.leaky_relu(x, 0.1)
+                if act_override is not None and ind in act_override:
+                    x = torch.where(act_override[ind] > 0, x, x * 0.1)
+                else:
+                    x = F.leaky_relu(x, 0.1)
             elif b['activation'] == 'relu':
                 x = F.relu(x)
         elif t == 'maxpool':

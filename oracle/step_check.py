@@ -12,8 +12,9 @@ returns the error of every quantity the step produces:
   conv      worst per-layer error of the product's raw conv outputs vs the oracle's convolution of the product's
             own layer inputs (layer-local, every conv launch of the step with the plan the autotuner picked)
   grad      worst per-parameter max-normalised error of the parameter gradients against the DECISION-FROZEN oracle
-            backward (forward_ref(raw_override=...): the oracle's autograd runs on the product's own raw conv outputs,
-            so batch statistics, leaky signs and max-pool winners are decided on identical numbers; strict bar).  A filter
+            backward (forward_ref(raw_override=..., act_override=...): the oracle's autograd runs on the product's own
+            raw conv outputs, so batch statistics and max-pool winners are decided on identical numbers, and every
+            element of an un-pooled leaky block takes the branch the product took; strict bar).  A filter
             gradient whose fp32 oracle value is itself inexact (ill-conditioned sum) is compared against the float64
             re-evaluation of the oracle's own operands instead ('grad_fp64_oracle' lists those and all three errors)
   grad_out  error of dL/d(head) (the RegionLoss gradient) against the oracle's on the product's head
@@ -103,6 +104,15 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             continue
         r = cs.raw.view(B, cs.H, cs.W, cs.ldraw)[..., :cs.cout].permute(0, 3, 1, 2)
         raws[ind] = r.contiguous().cpu()
+    # the product's activations of the un-pooled leaky blocks: their SIGN freezes the leaky branch per element in the
+    # oracle's backward (forward_ref(act_override=...)); the pooled blocks keep the oracle's own decisions
+    acts = {}
+    for ind, cs in plan.convs.items():
+        if cs.needs_act and not cs.pool and cs.slope == 0.1 and not getattr(cs, 'first_live', False):
+            a = cs.out
+            acts[ind] = a.t[a.off:].view(-1)[:B * a.H * a.W * a.ld].view(B, a.H, a.W, a.ld)[..., :cs.cout] \
+                .permute(0, 3, 1, 2).contiguous().cpu() if a.off == 0 else None
+    acts = {k: v for k, v in acts.items() if v is not None}
     loss = crit(out, tgt, epoch)
     loss.backward()
     torch.cuda.synchronize()
@@ -130,7 +140,9 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     # ---- decision-frozen oracle: per-layer conv check + whole-network gradients ----
     st_b = _clone(state0, requires_grad=True)
     own, tape = {}, {}
-    y_frozen = forward_ref(model.blocks, st_b, x_cpu, training=True, raw_override=raws, raws=own, tape=tape)
+    y_frozen = forward_ref(model.blocks, st_b, x_cpu, training=True, raw_override=raws, raws=own, tape=tape,
+                           act_override=acts)
+    res['frozen_leaky_layers'] = len(acts)
     res['conv_by_layer'] = {ind: _rel(raws[ind], own[ind]) for ind in sorted(raws)}
     res['conv'] = max(res['conv_by_layer'].values())
     r_frz = region_loss_ref(out_c, tgt, epoch, **loss_kwargs)        # loss gradient on the product's own head
@@ -167,11 +179,11 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     res['grad_by_param'] = gerr
     res['grad'] = max(gerr.values())
     if exact:
-        res.update(exact_frozen_errors(model, state0, st_b, x_cpu, raws, r_frz['grad']))
+        res.update(exact_frozen_errors(model, state0, st_b, x_cpu, raws, r_frz['grad'], acts))
     return res
 
 
-def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head):
+def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head, acts=None):
     """Float64 evaluation of the raw-output-frozen network (same overrides: the product's raw conv outputs, exactly
     representable in float64; batch statistics - and with them the leaky sign / pool winner of the few elements that sit
     within fp32 rounding of a decision boundary - are float64's) and, against it, the per-parameter distances of the
@@ -188,7 +200,7 @@ def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head):
                 d[k].requires_grad_(True)
         st64.append(d)
     y64 = forward_ref(model.blocks, st64, x_cpu.double(), training=True,
-                      raw_override={k: v.double() for k, v in raws.items()})
+                      raw_override={k: v.double() for k, v in raws.items()}, act_override=acts)
     y64.backward(grad_head.double())
     pairs = {}
     for ind, e in enumerate(st64):

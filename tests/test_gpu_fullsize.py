@@ -18,15 +18,18 @@ from helpers import GOLD, ROOT, load_state_into, make_targets
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-# Whole-network parameter gradients against the decision-frozen oracle.  Typical worst parameter: 2e-4 (the first layer's
-# ill-conditioned filter gradient, against the float64 re-evaluation), 2e-5 elsewhere.  The mean-subtraction constants of
-# BatchNorm-backward (mean(dy), a heavily cancelling sum) amplify the rounding difference between this path's and
-# oneDNN's data gradients, by an amount that depends on the summation order, i.e. on the autotuned plan set: the worst set
-# seen (tools/plansets/r02i_b64_setC.json, replayable with SSP_TUNE_CACHE) puts layer 24 at 6.8e-4 with bit-identical
-# conv outputs (tools/lean_vs_old.py).  1e-3 still sits 10x under the free-running fp32-vs-fp64 envelope of
-# tests/test_gpu_darknet.py and every kernel keeps its own 1e-4 test.  _assert_exact below adds a yardstick: measured
-# against a float64 evaluation of the same frozen network the product is exactly as far away as the fp32 oracle, parameter by parameter.
-GRAD_TOL = 1e-3
+# Whole-network parameter gradients against the decision-frozen oracle (raw conv outputs AND the leaky branch of every
+# element of the un-pooled blocks are the product's own: oracle/darknet_ref.py forward_ref(raw_override, act_override)).
+# Every parameter but one meets the north-star 1e-4 (measured worst: 2e-5).  The exception is the first layer's filter
+# gradient, sum(dx * image) with sum(dx) = 0 exactly over an all-positive image: the terms cancel ~1e3 : 1 at B = 64, the
+# fp32 oracle itself (oneDNN) sits 1.5e-3 from the float64 sum of its own operands, the product 2e-4 - its bar is 5e-4
+# against that float64 re-evaluation.
+# History: before the leaky branches were frozen a plan-set-dependent 6.8e-4 showed up on layer 24
+# (tools/plansets/r02i_b64_setC.json replays it): ONE element of that layer sits within fp32 rounding of y = 0, takes the
+# other leaky branch in the oracle's BatchNorm arithmetic than in the product's (scale * raw + shift), and happens to
+# carry most of its channel's gradient.  Both branches are valid fp32 results; the float64 yardstick (below) exposed it.
+GRAD_TOL = 1e-4
+GRAD_TOL_FIRST_FILTER = 5e-4
 
 
 def _report(tag, res):
@@ -42,15 +45,17 @@ def _assert_step(res):
     assert res['running'] < TOL, res['running']
     assert res['conv'] < TOL, res['conv_by_layer']
     assert res['grad_out'] < TOL, res['grad_out']
-    assert res['grad'] < GRAD_TOL, sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:5]
+    for name, err in res['grad_by_param'].items():
+        assert err < (GRAD_TOL_FIRST_FILTER if name == '0.weight' else GRAD_TOL), \
+            sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:5]
 
 
 def _assert_exact(res):
     """Against the FLOAT64 evaluation of the raw-output-frozen network (oracle/step_check.py: float64 re-decides the few
     leaky / pool elements that sit within fp32 rounding of a boundary, so it is a yardstick, not an exact value): every
     parameter gradient of the product is either within 1e-4 of it or no further from it than 3x the fp32 oracle
-    (PyTorch-CPU / oneDNN) is.  Measured: the two distances agree to 3 digits on the worst parameters (5.709e-4 vs
-    5.714e-4 on layer 8 at B = 64) - the HIP path sits where the reference's own arithmetic sits."""
+    (PyTorch-CPU / oneDNN) is.  Measured at B = 64 with the leaky branches frozen: every parameter <= 3e-5 on both sides,
+    except the first layer's filter gradient - product 3e-4, fp32 oracle 1.5e-3."""
     worst = sorted(res['grad64_by_param'].items(), key=lambda kv: -kv[1][0])[:4]
     print('vs float64 frozen backward: product %.2e, fp32 oracle %.2e | worst (product, oracle) %s' % (
         res['grad64'], res['grad64_ref'], worst))

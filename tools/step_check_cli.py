@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--opt', default='')
     ap.add_argument('--top', type=int, default=8)
     ap.add_argument('--epoch', type=int, default=20)
+    ap.add_argument('--exact', action='store_true', help='also the float64 yardstick (oracle/step_check.py)')
     args = ap.parse_args()
     from bench import synthetic_batch
     from oracle.step_check import check_train_step, summarize
@@ -31,11 +32,14 @@ def main():
     torch.manual_seed(0)
     model = Darknet(args.cfg).cuda()
     x, tgt = synthetic_batch(args.batch, args.size, args.size, 1000, 'cpu')
-    res = check_train_step(model, RegionLoss(), x, tgt, args.epoch)
+    res = check_train_step(model, RegionLoss(), x, tgt, args.epoch, exact=args.exact)
     worst = sorted(res['grad_by_param'].items(), key=lambda kv: -kv[1])[:args.top]
     print('STEPCHECK opt=%r env FIRST_FUSED=%s BN_FUSE=%s: %s' % (args.opt, os.environ.get('SSP_FIRST_FUSED', '1'),
                                                                     os.environ.get('SSP_BN_FUSE', '1'), summarize(res)))
     print('  worst grads:', [(k, float('%.3g' % v)) for k, v in worst])
+    if args.exact:
+        w64 = sorted(res['grad64_by_param'].items(), key=lambda kv: -kv[1][0])[:args.top]
+        print('  vs float64 (product, fp32 oracle):', [(k, float('%.3g' % a), float('%.3g' % b)) for k, (a, b) in w64])
     print('  plans:', [(i, f, d) for i, f, d in res['plans'] if f or d])
     print('  fp64 fallbacks:', {k: {a: float('%.3g' % b) for a, b in v.items()} for k, v in res.get('grad_fp64_oracle', {}).items()})
 
