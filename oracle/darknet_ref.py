@@ -72,7 +72,7 @@ def reorg_ref(x, stride=2):
 
 
 def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_override=None, raws=None, tape=None,
-                act_override=None):
+                act_override=None, pool_override=None):
     """Runs the layer list on CPU tensors.  `state` entries may require grad; running stats are updated in place
     when training.  Returns the raw head (and every layer output when keep=True).
 
@@ -91,7 +91,10 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
     evaluations in its last bits (scale * raw + shift against (raw - mean) * invstd * gamma + beta), so an element
     within ~1e-7 of zero can take different branches; when that element carries a large share of the gradient (the
     label's cell in the deep layers) one flipped branch moves a channel's gradient by 1e-3.  Both branches are valid
-    fp32 results - freezing the decision removes the ambiguity from the comparison."""
+    fp32 results - freezing the decision removes the ambiguity from the comparison.
+    pool_override {max-pool layer index: int64 (B,C,Ho,Wo) flat indices as F.max_pool2d(return_indices=True) yields}:
+    the window element the product's max-pool selected (first maximum of ITS activations); this function's activation
+    is gathered there instead of re-deciding the maximum on its own last bits."""
     outputs = {}
     for ind, b in enumerate(blocks[1:]):
         t = b['type']
@@ -119,7 +122,11 @@ def forward_ref(blocks, state, x, training, momentum=0.1, keep=False, raw_overri
             elif b['activation'] == 'relu':
                 x = F.relu(x)
         elif t == 'maxpool':
-            x = F.max_pool2d(x, int(b['size']), int(b['stride']))
+            if pool_override is not None and ind in pool_override:
+                idx = pool_override[ind]
+                x = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+            else:
+                x = F.max_pool2d(x, int(b['size']), int(b['stride']))
         elif t == 'reorg':
             x = reorg_ref(x, int(b['stride']))
         elif t == 'route':

@@ -113,6 +113,23 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             acts[ind] = a.t[a.off:].view(-1)[:B * a.H * a.W * a.ld].view(B, a.H, a.W, a.ld)[..., :cs.cout] \
                 .permute(0, 3, 1, 2).contiguous().cpu() if a.off == 0 else None
     acts = {k: v for k, v in acts.items() if v is not None}
+    # pooled blocks (but the fused first one, whose raw output is never stored): the product's own BN + leaky kernel once
+    # more WITHOUT the pooling, into a scratch buffer - its signs freeze the leaky branches, its first-maximum positions the
+    # pool winners (forward_ref(pool_override=...)).  Same kernel, same scale / shift vectors, same expression as the
+    # pooled launch of the forward pass and the recomputation in backward.
+    pools = {}
+    import torch.nn.functional as F
+    from singleshotpose_amd import _lib
+    for ind, cs in plan.convs.items():
+        if cs.pool and cs.needs_act and cs.slope == 0.1 and not getattr(cs, 'first_live', False) and cs.coutp == cs.cout:
+            scratch = torch.empty(cs.M * cs.coutp, dtype=torch.float32, device=dev)
+            v = cs.vec
+            _lib.call('ssp_bn_act_fwd', cs.raw.data_ptr(), cs.ldraw, scratch.data_ptr(), cs.coutp, v[2].data_ptr(),
+                      v[3].data_ptr(), cs.coutp, B, cs.H, cs.W, 0, cs.slope, torch.cuda.current_stream().cuda_stream)
+            a = scratch.view(B, cs.H, cs.W, cs.coutp).permute(0, 3, 1, 2).contiguous().cpu()
+            acts[ind] = a
+            pools[ind + 1] = F.max_pool2d(a, 2, 2, return_indices=True)[1]
+            del scratch
     loss = crit(out, tgt, epoch)
     loss.backward()
     torch.cuda.synchronize()
@@ -141,8 +158,8 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     st_b = _clone(state0, requires_grad=True)
     own, tape = {}, {}
     y_frozen = forward_ref(model.blocks, st_b, x_cpu, training=True, raw_override=raws, raws=own, tape=tape,
-                           act_override=acts)
-    res['frozen_leaky_layers'] = len(acts)
+                           act_override=acts, pool_override=pools)
+    res['frozen_leaky_layers'], res['frozen_pool_layers'] = len(acts), len(pools)
     res['conv_by_layer'] = {ind: _rel(raws[ind], own[ind]) for ind in sorted(raws)}
     res['conv'] = max(res['conv_by_layer'].values())
     r_frz = region_loss_ref(out_c, tgt, epoch, **loss_kwargs)        # loss gradient on the product's own head
@@ -179,11 +196,11 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     res['grad_by_param'] = gerr
     res['grad'] = max(gerr.values())
     if exact:
-        res.update(exact_frozen_errors(model, state0, st_b, x_cpu, raws, r_frz['grad'], acts))
+        res.update(exact_frozen_errors(model, state0, st_b, x_cpu, raws, r_frz['grad'], acts, pools))
     return res
 
 
-def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head, acts=None):
+def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head, acts=None, pools=None):
     """Float64 evaluation of the raw-output-frozen network (same overrides: the product's raw conv outputs, exactly
     representable in float64; batch statistics - and with them the leaky sign / pool winner of the few elements that sit
     within fp32 rounding of a decision boundary - are float64's) and, against it, the per-parameter distances of the
@@ -200,7 +217,7 @@ def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head, acts=None):
                 d[k].requires_grad_(True)
         st64.append(d)
     y64 = forward_ref(model.blocks, st64, x_cpu.double(), training=True,
-                      raw_override={k: v.double() for k, v in raws.items()}, act_override=acts)
+                      raw_override={k: v.double() for k, v in raws.items()}, act_override=acts, pool_override=pools)
     y64.backward(grad_head.double())
     pairs = {}
     for ind, e in enumerate(st64):

@@ -18,8 +18,9 @@ from helpers import GOLD, ROOT, load_state_into, make_targets
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-# Whole-network parameter gradients against the decision-frozen oracle (raw conv outputs AND the leaky branch of every
-# element of the un-pooled blocks are the product's own: oracle/darknet_ref.py forward_ref(raw_override, act_override)).
+# Whole-network parameter gradients against the decision-frozen oracle (raw conv outputs, the leaky branch of every
+# element and the winner of every pooling window are the product's own - all blocks but the fused first one:
+# oracle/darknet_ref.py forward_ref(raw_override, act_override, pool_override)).
 # Every parameter but one meets the north-star 1e-4 (measured worst: 2e-5).  The exception is the first layer's filter
 # gradient, sum(dx * image) with sum(dx) = 0 exactly over an all-positive image: the terms cancel ~1e3 : 1 at B = 64, the
 # fp32 oracle itself (oneDNN) sits 1.5e-3 from the float64 sum of its own operands, the product 2e-4 - its bar is 5e-4

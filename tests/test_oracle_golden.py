@@ -134,3 +134,48 @@ def test_eval_metrics_oracle_vs_reference_golden():
         got = np.array([pose_errors_ref(vertices, R_gt[i], t_gt[i], R_pr[i], t_pr[i], K) for i in range(6)])
         assert np.array_equal(got, g['errors_%d' % seed])
         assert pts_diameter_ref(pts) == float(g['diameter_%d' % seed][0])
+
+
+def test_decision_overrides_are_identities_on_own_decisions_and_local_when_flipped():
+    """forward_ref(act_override / pool_override) - the decision freezing oracle/step_check.py uses: fed the oracle's OWN
+    activations and pool winners it changes nothing (values and gradients bit-identical); with one element's leaky branch
+    flipped only that layer's channel moves."""
+    import torch.nn.functional as F
+    from oracle.darknet_ref import forward_ref, seeded_state
+    from singleshotpose_amd.cfg import parse_cfg
+    blocks = parse_cfg(os.path.join(GOLD, 'tiny-pose.cfg'))
+    base = seeded_state(blocks, 4)
+
+    def fresh():
+        return [None if e is None else {k: v.clone().requires_grad_(not k.startswith('running')) for k, v in e.items()}
+                for e in base]
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(1))
+    st0 = fresh()
+    y0, outs = forward_ref(blocks, st0, x, training=True, keep=True)
+    y0.sum().backward()
+    acts, pools = {}, {}
+    for ind, b in enumerate(blocks[1:]):
+        if b['type'] == 'convolutional' and b['activation'] == 'leaky':
+            acts[ind] = outs[ind].detach()
+        if b['type'] == 'maxpool':
+            pools[ind] = F.max_pool2d(outs[ind - 1].detach(), 2, 2, return_indices=True)[1]
+    assert acts and pools
+    st1 = fresh()
+    y1 = forward_ref(blocks, st1, x, training=True, act_override=acts, pool_override=pools)
+    y1.sum().backward()
+    assert torch.equal(y0, y1)
+    for a, b in zip(st0, st1):
+        if a is not None:
+            for k in a:
+                if not k.startswith('running'):
+                    assert torch.equal(a[k].grad, b[k].grad), k
+    # flip one element of the last leaky block: its filter gradient moves in that output channel only
+    last = max(acts)
+    flipped = dict(acts)
+    t = acts[last].clone()
+    t[0, 3, 1, 1] = -t[0, 3, 1, 1] if float(t[0, 3, 1, 1]) != 0 else 1.0
+    flipped[last] = t
+    st2 = fresh()
+    forward_ref(blocks, st2, x, training=True, act_override=flipped, pool_override=pools).sum().backward()
+    d = (st2[last]['weight'].grad - st0[last]['weight'].grad).abs().flatten(1).max(1)[0]
+    assert float(d[3]) > 0 and float(d.sum() - d[3]) == 0
