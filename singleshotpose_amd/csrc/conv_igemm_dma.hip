@@ -244,6 +244,11 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
   // covers that LDS latency instead.
   f32x4 fa0[2][TM], fb0[2][TN], fa1[TM], fb1[TN];
   read_frag(0, 0, fa0[0], fb0[0]);
+  // Enter the K loop with nothing but these in-order LDS reads on the compiler's lgkm scoreboard: the kernel-argument
+  // scalar loads of the prologue return out of order, and a loop header that may still have one pending makes the
+  // compiler wait lgkmcnt(0) before the first MFMA of every unrolled iteration - i.e. for the fragment reads it has
+  // just issued - instead of the counted lgkmcnt(n) the other steps get.  (vmcnt 63 / expcnt 7 = no wait on those.)
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // one K chunk; S = ring slot of the chunk being multiplied (compile time: LDS addresses become immediates)
   auto step = [&](auto slot_tag) {
