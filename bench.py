@@ -40,12 +40,8 @@ def synthetic_batch(B, H, W, seed, device):
     return x.to(device), t.view(B, -1)   # labels stay on the host (float64), as train.py:83 leaves them
 
 
-def cpu_baseline(cfgfile, B, H, W, budget_s=30.0):
-    """The same step on the CPU oracle (reference semantics, PyTorch-CPU kernels): forward, RegionLoss, backward.
-
-    A B = 8 step (the cfg's own batch, yolo-pose.cfg:3) does not scale to every hardware thread of a 2-socket host
-    (128 threads measured SLOWER than 8 in round 1): one warm-up + one timed step per thread count in {8, 16, 32, 64,
-    all}, then the best count is timed again (median of up to 3) and reported with the count that won."""
+def _cpu_port_step_fn(cfgfile, B, H, W):
+    """One training step on the CPU oracle (oracle/: the reference's semantics restated on PyTorch-CPU kernels)."""
     from oracle.darknet_ref import forward_ref, seeded_state
     from oracle.region_loss_ref import region_loss_ref
     from singleshotpose_amd.cfg import parse_cfg
@@ -68,11 +64,65 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=30.0):
                 for v in e.values():
                     v.grad = None
         return time.time() - t0
+    return one_step
 
+
+def _reference_times(cfgfile, B, size, threads, repeats=1, timeout=240):
+    """seconds per step of the REFERENCE's own Darknet + RegionLoss on this host's CPU for each thread count
+    (oracle/time_reference_cpu.py in its own process - it redirects torch.cuda.* to the CPU), or None."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'time_reference_cpu.py'), cfgfile, str(B), str(size),
+           ','.join(str(t) for t in threads), str(repeats)]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+    if 'seconds_per_step' not in rec:
+        return None
+    rec['seconds_per_step'] = {int(k): v for k, v in rec['seconds_per_step'].items()}
+    return rec
+
+
+def cpu_baseline(cfgfile, B, H, W, budget_s=30.0, big_batch=64):
+    """The same training step (forward, RegionLoss, backward) on this host's CPU cores - a reported baseline, not a target.
+
+    kind "reference": the reference's OWN modules (darknet.Darknet, region_loss.RegionLoss with the three torch >= 0.5
+    patches of SURVEY.md 8(c)), staged under oracle/_ref by oracle/stage_reference.py and timed in a separate process.
+    kind "port" (only when nothing was staged): the oracle/ restatement - the same ATen / oneDNN kernels underneath.
+
+    A B = 8 step (the cfg's own batch, yolo-pose.cfg:3) does not scale to every hardware thread of a 2-socket host
+    (128 threads measured SLOWER than 8 in round 1): one warm-up + one timed step per thread count in {8, 16, 32, 64,
+    all}, then the best count is timed again (median of 3) and reported with the count that won; the metric's own batch
+    (64) is timed at the two largest counts only (one warm-up + one step each: ~7 s per step)."""
     all_threads = torch.get_num_threads()
     ncpu = os.cpu_count() or all_threads
     cands = sorted(set(t for t in (8, 16, 32, 64, all_threads) if t <= max(all_threads, 8)))
     t_begin = time.time()
+    ref = _reference_times(cfgfile, B, H, cands)
+    if ref is not None:
+        sweep = ref['seconds_per_step']
+        best = min(sweep, key=sweep.get)
+        again = _reference_times(cfgfile, B, H, [best], repeats=3)
+        med = again['seconds_per_step'][best] if again else sweep[best]
+        res = {"value": round(B / med, 3), "unit": "images/s", "cores": int(best), "kind": "reference", "batch": B,
+               "sample": "reference darknet.Darknet + region_loss.RegionLoss (patched for torch >= 0.5, CPU): median of 3 "
+                         "steps of fwd+RegionLoss+bwd at batch %d, %dx%d with %d threads - the fastest of a one-step sweep "
+                         "over %s threads" % (B, H, W, best, sorted(sweep)),
+               "modules": ref['modules'],
+               "sweep_images_per_s": {str(k): round(B / v, 3) for k, v in sorted(sweep.items())}, "host_cpus": ncpu}
+        if big_batch and big_batch != B and time.time() - t_begin < budget_s + 30:
+            big = _reference_times(cfgfile, big_batch, H, sorted(set(cands[-2:])), timeout=300)
+            if big is not None:
+                bs = big['seconds_per_step']
+                bb = min(bs, key=bs.get)
+                res["batch%d" % big_batch] = {"value": round(big_batch / bs[bb], 3), "unit": "images/s", "cores": int(bb),
+                                              "sample": "1 step after 1 warm-up at batch %d, threads %s" % (big_batch, sorted(bs)),
+                                              "sweep_images_per_s": {str(k): round(big_batch / v, 3) for k, v in sorted(bs.items())}}
+        res["seconds"] = round(time.time() - t_begin, 1)
+        return res
+    one_step = _cpu_port_step_fn(cfgfile, B, H, W)
     sweep = {}
     for nt in cands:
         torch.set_num_threads(nt)
@@ -89,8 +139,9 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=30.0):
     torch.set_num_threads(all_threads)
     med = float(np.median(times))
     return {"value": round(B / med, 3), "unit": "images/s", "cores": int(best), "kind": "port", "batch": B,
-            "sample": "%d steps of fwd+RegionLoss+bwd at batch %d, %dx%d (median) with %d threads - the fastest of a "
-                      "one-step sweep over %s threads" % (len(times), B, H, W, best, sorted(sweep)),
+            "sample": "oracle/ restatement (no oracle/_ref/modules.zip staged): %d steps of fwd+RegionLoss+bwd at batch %d, "
+                      "%dx%d (median) with %d threads - the fastest of a one-step sweep over %s threads"
+                      % (len(times), B, H, W, best, sorted(sweep)),
             "sweep_images_per_s": {str(k): round(B / v, 3) for k, v in sorted(sweep.items())},
             "host_cpus": ncpu}
 
@@ -208,6 +259,71 @@ def extras(device, steps=5):
     return out
 
 
+def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
+    """SURVEY.md 8(f) row 2 (train.py after epoch 10 draws H = W from 224..832 every 10 batches, dataset.py:66-90): the
+    training step at other resolutions - images/s and conv-FLOP fraction of the fp32-MFMA peak (87.673 GFLOP per image
+    scales with the pixel count) - and what the FIRST visit of a new shape costs (plan build + per-launch autotune +
+    verify-after-tune, forward and backward) with (a) nothing cached, (b) the timed choices known (what a process started
+    with SSP_TUNE_CACHE=<file> sees: choices loaded, each verified once), (c) choices known and verified (a shape whose
+    plan was evicted from the LRU and is rebuilt)."""
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.optim import SGD
+    from singleshotpose_amd.region_loss import RegionLoss
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).to(device).train()
+    crit = RegionLoss()
+    crit.verbose = False
+    opt = SGD(model.parameters(), lr=1e-3 / B, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    out = {}
+    for size in sizes:
+        x, tgt = synthetic_batch(B, size, size, 2000 + size, device)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            crit(model(x), tgt, 20).backward()
+            opt.step()
+
+        def first_visit():
+            model._plans.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+
+        keep = dict(engine._TUNE_CACHE), set(engine._TUNE_VERIFIED)
+        engine._TUNE_CACHE.clear()
+        engine._TUNE_VERIFIED.clear()
+        cold = first_visit()
+        engine._TUNE_VERIFIED.clear()
+        warm_file = first_visit()
+        rebuilt = first_visit()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        engine._TUNE_CACHE.update(keep[0])
+        engine._TUNE_VERIFIED.update(keep[1])
+        flop = 87.673e9 * (size / 416.0) ** 2
+        plan = next(iter(model._plans.values()))
+        out['train_%d_b%d' % (size, B)] = {
+            "workload": "cfg/yolo-pose.cfg train step, %dx%d, batch %d" % (size, size, B),
+            "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1),
+            "step_conv_flop_frac_of_peak": round(B / dt * flop / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "first_visit_ms": {"cold_tune_cache": round(cold, 1), "warm_tune_cache_unverified": round(warm_file, 1),
+                               "warm_tune_cache_verified": round(rebuilt, 1)},
+            "tuned_launches": sum(1 for cs in plan.convs.values() if cs.plan_fwd or cs.plan_dgrad)}
+        del x
+        model._plans.clear()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -316,6 +432,30 @@ def main():
     bms = [float(np.median([p[0][k] for p in per_step])) * nb for k in range(nk)]
     bwork = [float(np.median([p[1][k] for p in per_step])) * nb for k in range(nk)]
     bcnt = [float(np.median([p[2][k] for p in per_step])) * nb for k in range(nk)]
+    # Kernel-exclusive durations of the BACKWARD conv families: the same steps once more with the filter gradients queued
+    # on the main stream (Plan.serial_backward) - every launch then runs alone, as the forward launches always do, and its
+    # HIP-event duration is the kernel's own (in the real step dgrad and wgrad share the CUs on two streams and stretch
+    # each other's events: that pair is `roofline_bwd`).  Untimed, after the measurement; same operands, same plans.
+    for plan in model._plans.values():
+        plan.serial_backward = True
+    ex_step = []
+    for _ in range(3):
+        _lib.call('ssp_prof_enable', 0b110)
+        loss = step()
+        barrier()
+        _lib.call('ssp_prof_enable', 0)
+        ex_step.append(collect())
+    for plan in model._plans.values():
+        plan.serial_backward = False
+    ex = {k: (float(np.median([p[0][k] for p in ex_step])), float(np.median([p[1][k] for p in ex_step])),
+              float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2)}
+    if world > 1:
+        # communication diagnostics (untimed): per-bucket all-reduce issue -> done times and the exposed tail of one step
+        reducer.profile = True
+        loss = step()
+        barrier()
+        reducer.profile = False
+        comm = reducer.report()
     final_loss = float(loss)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -327,9 +467,8 @@ def main():
         kinds = _lib.PROF_KINDS
         prof = {kinds[k]: {"ms_per_step": bms[k] / nb, "launches_per_step": bcnt[k] / nb,
                            "work_per_step": bwork[k] / nb} for k in range(nk)}
-        # Dominant kernel = the implicit-GEMM conv kernel.  Its FORWARD launches run alone on the GPU, so their HIP-event
-        # durations are kernel-exclusive; the same kernel's data-gradient launches overlap the filter-gradient kernel
-        # on a second stream (Plan.backward), which stretches both their event durations - they are reported apart.
+        # Dominant kernel family = the implicit-GEMM conv kernel.  Its FORWARD launches run alone on the GPU, so their
+        # HIP-event durations are kernel-exclusive and are taken INSIDE the timed region.
         ig_ms, ig_flop, ig_n, ig_steps = ms[0], work[0], cnt[0], args.steps
         if ig_ms <= 0:      # --timers none: take the forward launches of the breakdown pass
             ig_ms, ig_flop, ig_n, ig_steps = bms[0], bwork[0], bcnt[0], nb
@@ -338,6 +477,13 @@ def main():
         bwd_tf = (bwork[1] + bwork[2]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         traffic, traffic_src = forward_traffic_per_launch()
         images_per_s = global_batch * args.steps / dt
+
+        def family(kernel, ms_, flop_, n_, note):
+            tf = flop_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "avg_launch_ms": round(ms_ / max(n_, 1), 4), "launches_per_step": n_,
+                    "ms_per_step": round(ms_, 3), "flop_per_step": flop_, "note": note}
         res = {
             "metric": "images/sec (fwd+bwd) yolo-pose 416x416 bs=64/GPU",
             "value": round(images_per_s, 2),
@@ -354,29 +500,47 @@ def main():
             "config": {"workload": "cfg/yolo-pose.cfg train step (zero_grad+fwd+RegionLoss+bwd+grad all-reduce+SGD), "
                                    "%dx%d, batch %d/GPU, random-init weights, 1 label/image" % (H, W, B),
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_dma_kernel<*,*,0,...> / conv_igemm_kernel forward launches",
+            # headline fraction of the step: ALL conv FLOPs of fwd+bwd (87.673 GFLOP per image) over the whole step's
+            # wall time - BatchNorm / activation / loss / optimizer time included in the denominator
+            "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv_igemm_dma_kernel<BM, BN, 0, NSLOT, WM, WN>(ConvArgs): the forward launches of "
+                                   "layers 2-30 (the first block's two passes are first_block_kernel<0|1>, reported under "
+                                   "kernel_ms_per_step.first_block_fwd, not here)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
                          "launches_per_step": ig_n / ig_steps,
-                         "flop_per_launch_avg": ig_flop / max(ig_n, 1)},
-            "roofline_bwd": {"bound": "mfma", "kernel": "conv dgrad (stream 1) overlapped with conv_wgrad_kernel (stream 2)",
+                         "flop_per_launch_avg": ig_flop / max(ig_n, 1),
+                         "note": "HIP events around exactly these launches inside the timed region (they run alone on the GPU)"},
+            "roofline_dgrad": family("conv_igemm_dma_kernel<BM, BN, 1, NSLOT, WM, WN>(ConvArgs) (+ conv_igemm_kernel<64, 128, "
+                                     "2, 2, 4, 0, 1> for the 20-channel head)", ex[1][0], ex[1][1], ex[1][2],
+                                     "kernel-exclusive: untimed pass with the filter gradients on the same stream "
+                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues"),
+            "roofline_wgrad": family("conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs)", ex[2][0], ex[2][1],
+                                     ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same stream "
+                                     "(Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
+                                     "(kernel_ms_per_step.first_block_bwd)"),
+            "roofline_bwd": {"bound": "mfma", "kernel": "in the real step: conv dgrad launches (main stream) overlapped with "
+                                                        "conv_wgrad_dma_kernel launches (second stream)",
                              "achieved": round(bwd_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(bwd_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                              "note": "algorithmic dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times); "
                                      "from a separate untimed pass with every launch timed, as kernel_ms_per_step"},
-            "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()},
             "final_loss": final_loss,
             "verified": verified,
             "verify": verify_detail,
         }
+        if world > 1:
+            res["comm"] = comm
         if world == 1 and not args.no_extras:
             del opt, x
             model._plans.clear()
             torch.cuda.empty_cache()
             res["extra"] = extras(device)
+            res["extra"].update(multiscale_extras(device))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cfg, args.cpu_batch, H, W)
         print(json.dumps(res))

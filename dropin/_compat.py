@@ -11,10 +11,19 @@ import torch
 _orig_array = torch.Tensor.__array__
 
 
-def _array_04(self, dtype=None):
-    t = self.detach().cpu() if (self.is_cuda or self.requires_grad) else self
+def _array_04(self, dtype=None, copy=None):
+    """NumPy 2 passes `copy=`: a device tensor always comes back as a fresh host array, so only copy=False on a tensor
+    that had to be moved cannot be honoured (numpy's own rule: raise)."""
+    moved = self.is_cuda or self.requires_grad
+    if moved and copy is False:
+        raise ValueError("a %s tensor cannot be viewed as a numpy array without a copy" % self.device)
+    t = self.detach().cpu() if moved else self
     return _orig_array(t) if dtype is None else _orig_array(t, dtype)
 
 
-if getattr(torch.Tensor.__array__, '__name__', '') != '_array_04':
+# SSP_DROPIN_ARRAY_COMPAT=0 leaves torch.Tensor.__array__ alone (the reference's drivers then need torch 0.4 semantics from
+# elsewhere); default on: the shims exist to run those drivers unchanged.
+import os
+if os.environ.get('SSP_DROPIN_ARRAY_COMPAT', '1') != '0' and \
+        getattr(torch.Tensor.__array__, '__name__', '') != '_array_04':
     torch.Tensor.__array__ = _array_04

@@ -230,7 +230,7 @@ int ssp_pts_diameter(const double* pts, int N, double* out, double* scratch, voi
 
 /* ---- timed-launch bookkeeping (bench.py roofline): HIP events around every launch of a kernel family -------- */
 /* mask: bit k = kernel family k (0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 BN/activation, 4 layout, 5 region/pnp/eval,
- * 6 optimizer); -1 = all, 0 = off.  Every timed launch costs two event packets on its stream. */
+ * 6 optimizer, 7 first block forward passes, 8 first block backward passes); -1 = all, 0 = off.  Every timed launch costs two event packets on its stream. */
 int ssp_prof_enable(int mask);
 /* ms[k], work[k] (FLOPs or bytes), count[k] for k in 0..ssp_prof_nkinds()-1; synchronises on the recorded events */
 int ssp_prof_nkinds(void);

@@ -3,7 +3,7 @@
 reference (oracle/run_reference_cpu.py) over the synthetic LINEMOD-shaped fixture (tests/fixture_linemod.py).
 
 Build container only:  python oracle/gen_dropin_golden.py      -> tests/golden/dropin_valid.json, dropin_train.json
-Also stages the reference's driver scripts for the GPU box (stage_callers): see its docstring.
+Also stages the reference's driver scripts for the GPU box (oracle/stage_reference.py).
 """
 import json
 import os
@@ -11,33 +11,19 @@ import shutil
 import subprocess
 import sys
 import tempfile
-import zipfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-CALLERS = ('valid.py', 'train.py', 'dataset.py', 'image.py', 'MeshPly.py')
 TRAIN_EPOCHS = 2
 
 
 def stage_callers():
-    """oracle/_ref/callers.zip <- the reference's driver scripts (valid.py, train.py) and the three helper modules they
-    import that are OUT of this repo's scope (dataset.py, image.py, MeshPly.py: the PIL data pipeline and the mesh
-    reader), byte for byte, so that the GPU box - which has no /root/reference - can EXECUTE the reference's unchanged
-    drivers against the drop-in.  Like a compiled oracle/_ref artefact: git-ignored (never enters history), not
-    gpurun-ignored (travels with the snapshot), rebuilt by __graft_entry__.build() whenever /root/reference is there.
-    darknet.py, region_loss.py, utils.py, cfg.py are deliberately NOT staged: those names resolve to dropin/."""
-    if not os.path.isdir(REF):
-        return None
-    dst = os.path.join(ROOT, 'oracle', '_ref')
-    os.makedirs(dst, exist_ok=True)
-    path = os.path.join(dst, 'callers.zip')
-    with zipfile.ZipFile(path, 'w', zipfile.ZIP_DEFLATED) as z:
-        for name in CALLERS:
-            z.write(os.path.join(REF, name), name)
-    return path
+    """Kept for callers of the old name: the staging lives in oracle/stage_reference.py."""
+    from oracle.stage_reference import stage
+    return stage()
 
 
 def main():

@@ -251,9 +251,37 @@ def gen_eval():
     print('eval_metrics', rec['errors_0'][:2], rec['diameter_0'])
 
 
+def gen_nms():
+    """bbox_iou / nms golden vectors from the reference's own multi_obj_pose_estimation/utils_multi.py:125-156,223-241."""
+    import_reference()
+    sys.path.insert(0, os.path.join(REF, 'multi_obj_pose_estimation'))
+    import utils_multi as ref_utils_multi
+    rs = np.random.RandomState(21)
+    rec = {}
+    for case, n in enumerate((1, 7, 24)):
+        b = np.concatenate([rs.uniform(0.2, 0.8, (n, 2)), rs.uniform(0.1, 0.5, (n, 2)), rs.uniform(0.0, 1.0, (n, 1)),
+                            rs.uniform(0.0, 1.0, (n, 1)), rs.randint(0, 13, (n, 1)).astype(np.float64)], axis=1)
+        if n > 4:
+            b[3, 4] = 0.0                    # a box that is already suppressed
+            b[5, :4] = b[2, :4]              # an exact duplicate (IoU 1)
+        boxes = [list(map(float, r)) for r in b]
+        kept = ref_utils_multi.nms(boxes, 0.4)
+        rec['in_%d' % case] = b
+        rec['kept_%d' % case] = np.array(kept, dtype=np.float64).reshape(len(kept), -1)
+        rec['after_%d' % case] = np.array(boxes, dtype=np.float64)          # nms zeroes det_conf in place
+        rec['iou_%d' % case] = np.array([[ref_utils_multi.bbox_iou(x, y, x1y1x2y2=False) for y in b] for x in b], dtype=np.float64)
+        rec['iou_xyxy_%d' % case] = np.array([[ref_utils_multi.bbox_iou(np.sort(x[:4]), np.sort(y[:4]), x1y1x2y2=True)
+                                               for y in b] for x in b], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, 'nms.npz'), **rec)
+    print('nms', [rec['kept_%d' % c].shape for c in range(3)])
+
+
 if __name__ == '__main__':
     if '--eval' in sys.argv:
         gen_eval()
+    elif '--nms' in sys.argv:
+        gen_nms()
     else:
         main()
         gen_eval()
+        gen_nms()

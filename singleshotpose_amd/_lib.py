@@ -75,7 +75,8 @@ _SIGS = {
 
 _RET64 = ('ssp_conv_workspace_floats',)
 
-PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim")
+PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
+              "first_block_bwd")
 
 
 def csrc_digest():

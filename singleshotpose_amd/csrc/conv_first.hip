@@ -339,7 +339,7 @@ int ssp_first_fwd_stats_launch(const float* x, const float* wt, float* stats, in
   if (int rc = first_check(x, wt, B, H, W, "first_fwd_stats")) return rc;
   FirstArgs a = first_args(x, wt, B, H, W, 16);
   a.stats = stats;
-  SspProfScope prof(SSP_PROF_CONV_FWD, stream, 2.0 * (double)B * H * W * FIRST_COUT * 27.0);   // algorithmic: 3 real input channels
+  SspProfScope prof(SSP_PROF_FIRST_FWD, stream, 2.0 * (double)B * H * W * FIRST_COUT * 27.0);   // algorithmic conv FLOPs (3 real input channels), booked once per direction
   hipLaunchKernelGGL(first_block_kernel<0>, dim3(ssp_cdiv(a.nblocks, 64)), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_fwd_stats");
   return SSP_OK;
@@ -352,7 +352,7 @@ int ssp_first_fwd_apply_launch(const float* x, const float* wt, const float* sca
                 "first_fwd_apply: bad output (ldo >= 32, < 2 GiB)");
   FirstArgs a = first_args(x, wt, B, H, W, 16);
   a.scale = scale; a.shift = shift; a.slope = slope; a.out = out; a.ldo = ldo;
-  SspProfScope prof(SSP_PROF_BN_ACT, stream, 0.0);
+  SspProfScope prof(SSP_PROF_FIRST_FWD, stream, 0.0);
   hipLaunchKernelGGL(first_block_kernel<1>, dim3(ssp_cdiv(a.nblocks, 64)), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_fwd_apply");
   return SSP_OK;
@@ -379,7 +379,7 @@ int ssp_first_bwd_reduce_launch(const float* x, const float* wt, const float* g,
   FirstArgs a = first_args(x, wt, B, H, W, 16);
   a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.slope = slope; a.g = g; a.ldg = ldg;
   a.stats = partial;
-  SspProfScope prof(SSP_PROF_BN_ACT, stream, 0.0);
+  SspProfScope prof(SSP_PROF_FIRST_BWD, stream, 0.0);
   hipLaunchKernelGGL(first_block_kernel<2>, dim3(ssp_cdiv(a.nblocks, 64)), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_bwd_reduce");
   return SSP_OK;
@@ -394,7 +394,7 @@ int ssp_first_bwd_wgrad_launch(const float* x, const float* wt, const float* g, 
   FirstArgs a = first_args(x, wt, B, H, W, 64);
   a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2; a.slope = slope;
   a.g = g; a.ldg = ldg; a.dw = dw;
-  SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)B * H * W * FIRST_COUT * 27.0);
+  SspProfScope prof(SSP_PROF_FIRST_BWD, stream, 2.0 * (double)B * H * W * FIRST_COUT * 27.0);
   hipLaunchKernelGGL(first_block_kernel<3>, dim3(ssp_cdiv(a.nblocks, 256)), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_bwd_wgrad");
   return SSP_OK;

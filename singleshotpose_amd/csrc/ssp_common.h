@@ -43,7 +43,9 @@ enum SspProfKind {
   SSP_PROF_LAYOUT = 4,     // repack / transpose / reorg / maxpool
   SSP_PROF_REGION = 5,     // region loss / decode / pnp
   SSP_PROF_OPTIM = 6,      // fused SGD step
-  SSP_PROF_NKINDS = 7
+  SSP_PROF_FIRST_FWD = 7,  // first block, fused with recompute (conv_first.hip): statistics pass + apply pass
+  SSP_PROF_FIRST_BWD = 8,  // first block: BatchNorm-backward reduce pass + filter-gradient pass
+  SSP_PROF_NKINDS = 9
 };
 
 struct SspProfScope {

@@ -78,6 +78,7 @@ class Darknet(nn.Module):
         self.seen = 0
         self.iter = 0
         self._plans = collections.OrderedDict()
+        self._flat_grads = {}       # device -> flat gradient buffer shared by every plan's backward (engine.Plan.backward)
         self._bn_epoch = 0          # bumped by every training-mode forward (engine.Plan: inference BN constants key)
         self._max_plans = 32
         # eval forward as one captured hipGraph replay (Plan.forward_graph).  Opt-in: measured no gain on MI355X - the

@@ -9,7 +9,8 @@ Gradients of one backward live in ONE flat fp32 buffer laid out in reverse layer
 bucket is a contiguous slice: as soon as enough trailing layers have finished, its all-reduce is issued asynchronously
 (torch.distributed's RCCL stream orders itself after the work already queued on the compute stream) and overlaps the
 remaining wgrad/dgrad kernels.  xGMI is point-to-point: a ring all-reduce of the 202 MB gradient is bound by one
-~153 GB/s link (~2.3 ms) against a ~50 ms step, so a handful of large buckets is the right shape.
+~153 GB/s link (~2.3 ms) against a ~47 ms step, so a handful of large buckets is the right shape - with a SMALL last one,
+because only the last bucket cannot overlap anything (GradReducer's tail rule).
 """
 import os
 
@@ -30,17 +31,27 @@ def init_distributed(backend=None):
 
 
 class GradReducer(object):
-    """Bucketed all-reduce(SUM) of the flat gradient buffer, fed by Plan.backward as layers finish."""
+    """Bucketed all-reduce(SUM) of the flat gradient buffer, fed by Plan.backward as layers finish.
 
-    def __init__(self, model=None, world_size=None, bucket_bytes=48 << 20, group=None, force=False):
+    Buckets are contiguous slices in backward (reverse layer) order.  A bucket closes when it holds >= bucket_bytes, and
+    - the tail rule - as soon as what is still to come is <= tail_bytes: the last all-reduce can only start when the
+    backward pass ends, so it is kept small (yolo-pose.cfg: 47 / 38 / 38 / 40 / 36 MB buckets while the 13 x 13 and 26 x 26
+    layers run, then 3 MB for layers 0-10 instead of a 60 MB bucket exposed after the last wgrad)."""
+
+    def __init__(self, model=None, world_size=None, bucket_bytes=32 << 20, group=None, force=False, tail_bytes=4 << 20):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.tail_elems = max(0, tail_bytes // 4)
         self.group = group
         self.force = force      # exercise the collective path even on one rank (tests)
         self._pending = []
         self._flat = None
         self._lo = self._hi = 0
+        self._tail_closed = False
         self.launched = []     # (lo, hi) of every bucket of the last backward (introspection / tests)
+        self.profile = False   # record HIP events per bucket (bench.py's untimed diagnostic steps)
+        self._events = []      # (lo, hi, issue event, done event) of the last profiled step
+        self._join = None      # (backward-complete event, all-buckets-complete event) of the last profiled step
         if model is not None:
             model._reducer = self
             for plan in getattr(model, '_plans', {}).values():
@@ -54,28 +65,73 @@ class GradReducer(object):
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        self._pending.append(dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        ev = None
+        if self.profile:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()            # on the stream the bucket's last filter gradient was queued on
+        work = dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, lo, hi, ev))
+
+    def begin(self, flat):
+        """A backward pass starts writing gradients into `flat` (Plan.backward)."""
+        if not self.active:
+            return
+        if self._pending:      # a previous backward's buckets were never joined (no all_reduce() call): join them now
+            self.all_reduce()
+        self._flat, self._lo, self._hi, self._tail_closed = flat, None, None, False
+        self.launched = []
 
     def layer_done(self, flat, lo, hi):
         """Gradients flat[lo:hi] are complete (queued on the current stream); ranges arrive in increasing order."""
         if not self.active:
             return
-        if self._flat is not flat:
-            self._flat, self._lo, self._hi = flat, lo, lo
-            self.launched = []
+        if self._flat is not flat or self._lo is None:
+            if self._flat is not flat:
+                self.begin(flat)
+            self._lo = self._hi = lo
         assert lo == self._hi, "layers must finish in flat-buffer order"
         self._hi = hi
-        if self._hi - self._lo >= self.bucket_elems:
+        remaining = flat.numel() - hi
+        close_tail = (not self._tail_closed) and 0 < remaining <= self.tail_elems
+        if self._hi - self._lo >= self.bucket_elems or close_tail:
             self._launch(self._lo, self._hi)
             self._lo = self._hi
+            self._tail_closed = self._tail_closed or close_tail
 
     def all_reduce(self):
         """Flush the open bucket and make the current stream wait for every outstanding all-reduce."""
         if not self.active or self._flat is None:
             return
-        self._launch(self._lo, self._hi)
-        self._lo = self._hi
-        for w in self._pending:
-            w.wait()
+        if self._lo is not None:
+            self._launch(self._lo, self._hi)
+            self._lo = self._hi
+        t0 = None
+        if self.profile:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()            # the current stream has joined the backward pass: everything before this is compute
+            self._events = []
+        for work, lo, hi, ev in self._pending:
+            work.wait()
+            if self.profile:
+                done = torch.cuda.Event(enable_timing=True)
+                done.record()
+                self._events.append((lo, hi, ev, done))
+        if self.profile:
+            self._join = (t0, self._events[-1][3] if self._events else t0)
         self._pending = []
         self._flat = None
+
+    def report(self):
+        """Diagnostics of the last profiled step (after a synchronize): per bucket the bytes and the time from its issue
+        (last filter gradient of the bucket queued) to its completion as seen by the compute stream - queueing behind
+        earlier buckets included - and the exposed tail: how long the compute stream sat waiting for collectives after
+        the backward pass had ended."""
+        out = {"backend": dist.get_backend(self.group) if dist.is_initialized() else None, "ranks": self.world,
+               "bucket_bytes": self.bucket_elems * 4, "tail_bytes": self.tail_elems * 4,
+               "buckets_bytes": [(hi - lo) * 4 for lo, hi in self.launched]}
+        if self._events and self._join is not None:
+            torch.cuda.synchronize()
+            out["bucket_issue_to_done_ms"] = [round(ev.elapsed_time(done), 3) if ev is not None else None
+                                              for _, _, ev, done in self._events]
+            out["exposed_tail_ms"] = round(self._join[0].elapsed_time(self._join[1]), 3)
+        return out

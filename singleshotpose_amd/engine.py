@@ -57,6 +57,24 @@ def _tune_cache_save():
         os.replace(tmp, path)
 
 
+def _storage_refs(t):
+    """Reference count of t's storage (the tensor itself, every live view of it, the Python storage wrapper), or None
+    when this torch build does not expose it."""
+    fn = getattr(torch._C, '_storage_Use_Count', None)
+    return fn(t.untyped_storage()._cdata) if fn is not None else None
+
+
+def _storage_shared(t, refs_alone, params):
+    """True when something besides `t` itself still views t's storage (refs_alone = _storage_refs(t) right after t was
+    allocated).  Without the storage counter: true when a parameter's .grad aliases it (views held elsewhere are then
+    not seen: the conservative answer would cost a 202 MB allocation per backward)."""
+    refs = _storage_refs(t)
+    if refs is not None and refs_alone is not None:
+        return refs != refs_alone
+    sp = t.untyped_storage().data_ptr()
+    return any(p.grad is not None and p.grad.untyped_storage().data_ptr() == sp for p in params)
+
+
 def weights_changed():
     _WEIGHTS_EPOCH[0] += 1
 
@@ -89,7 +107,18 @@ class _Act(object):
 
 
 class _ConvSpec(object):
-    pass
+    """One conv block of a plan.  `raw` (the block's raw conv output, kept for backward) is allocated on first use: the
+    fused first block (csrc/conv_first.hip) recomputes its convolution in every pass and never touches it - 1.42 GB at
+    batch 64, 416 x 416 that a plan (and the plan cache's memory budget) does not have to carry."""
+    _raw = None
+    _raw_spec = None     # (allocator, floats, tensor kwargs)
+
+    @property
+    def raw(self):
+        if self._raw is None:
+            alloc, n, kw = self._raw_spec
+            self._raw = alloc(n, **kw)
+        return self._raw
 
 
 class Plan(object):
@@ -169,7 +198,7 @@ class Plan(object):
                 M = B * cs.H * cs.W
                 cs.M = M
                 alloc = torch.empty if cs.coutp == c else torch.zeros
-                cs.raw = alloc(M * cs.coutp, **f32)            # raw conv output (kept for backward)
+                cs._raw_spec = (alloc, M * cs.coutp, f32)      # raw conv output (kept for backward), see _ConvSpec.raw
                 cs.ldraw = cs.coutp
                 cs.needs_act = cs.bn or cs.slope != 1.0
                 if cs.needs_act:
@@ -287,6 +316,8 @@ class Plan(object):
         self.grad_total = goff
         self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
         self.side_stream = None
+        self.serial_backward = False   # measurement aid (bench.py): filter gradients on the MAIN stream, so that every
+                                       # backward launch runs alone and its HIP-event duration is kernel-exclusive
         self.dgrad_ready = None
         self.grads = {}      # layer index -> _Act gradient buffers, allocated on first backward
         self.out_act = self.acts[self.last]
@@ -295,11 +326,14 @@ class Plan(object):
         self._graph_failed = False
 
     def footprint(self):
-        """Bytes of device memory this plan's forward buffers hold (each storage counted once)."""
+        """Bytes of device memory this plan's forward buffers hold or will hold after a training-mode forward (each storage
+        counted once; raw conv outputs are allocated on first use - every block's but the fused first one's count here)."""
         seen, total = set(), 0
         ts = [self.x_nhwc, self.ws, self.bn_partial] + [a.t for a in self.acts if a is not None]
         for cs in self.convs.values():
-            ts += [cs.raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None)]
+            ts += [cs._raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None)]
+            if cs._raw is None and not getattr(cs, 'first_fused', False):
+                total += cs._raw_spec[1] * 4
         for t in ts:
             if t is not None and t.data_ptr() not in seen:
                 seen.add(t.data_ptr())
@@ -317,15 +351,24 @@ class Plan(object):
             cs.gbuf = torch.empty(cs.cout * cs.k * cs.k * cs.cinp, dtype=torch.float32, device=self.device)
         return cs.gbuf
 
-    def _prepare_backward(self):
+    def _prepare_backward(self, tune=True):
         """First forward that will be followed by a backward: data-gradient operand buffer, dgrad plan tuning, and the
-        split-K workspace those plans need."""
+        split-K workspace those plans need.
+
+        tune=False (Plan.backward's fallback, entered when the forward ran without gradient bookkeeping): the saved raw
+        conv outputs are live - timing / verify-after-tune launches would overwrite them (they randomise their operands)
+        - so the data-gradient launches only take choices that were timed AND verified earlier in this process, else the
+        library's heuristic; a later forward with need_grad tunes them."""
         if self._dpack is None:
             self._dpack = torch.empty(self._dpack_floats, dtype=torch.float32, device=self.device)
         if not self._dgrad_tuned:
-            self._dgrad_tuned = True
-            if self._tune:
+            self._dgrad_tuned = tune
+            if self._tune and tune:
                 self._autotune('dgrad')
+            elif self._tune:
+                for cs in self.convs.values():
+                    key = self._dgrad_key(cs)
+                    cs.plan_dgrad = _TUNE_CACHE.get(key, 0) if key in _TUNE_VERIFIED else 0
             need = 1
             for cs in self.convs.values():
                 cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
@@ -337,6 +380,9 @@ class Plan(object):
                 self.ws_floats = need
                 self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
                 self._graph = None          # a captured inference chain holds the old workspace pointer
+
+    def _dgrad_key(self, cs):
+        return ('dgrad', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld)
 
     def _plan_bn_fusion(self):
         """BatchNorm-backward reductions folded into the producing data-gradient launch (ssp_conv_dgrad_bnbwd).
@@ -454,8 +500,11 @@ class Plan(object):
             """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands."""
             if code == 0 or not verify or key in _TUNE_VERIFIED:
                 return code
+            # Operands are the plan's own buffers (they hold no data yet: tuning runs before the first forward, and
+            # Plan.backward's fallback never tunes).  Only the columns a launch owns are randomised: the channel padding of
+            # a torch.zeros-allocated activation must stay zero for its consumers.
             for t in operands:
-                t.uniform_(-1.0, 1.0, generator=gen)
+                (t[0].view(-1, t[1])[:, t[2]:t[2] + t[3]] if isinstance(t, tuple) else t).uniform_(-1.0, 1.0, generator=gen)
             res = []
             for c in (0, code):
                 launch(c)
@@ -474,6 +523,9 @@ class Plan(object):
                 return code
             TUNE_REJECTED.append((key, code))
             _TUNE_CACHE[key] = 0
+            import warnings
+            warnings.warn("singleshotpose_amd: verify-after-tune refused plan %d for launch %s (result differs from the "
+                          "default plan's); the default plan runs" % (code, key))
             return 0
 
         for cs in elig:
@@ -499,10 +551,11 @@ class Plan(object):
                     return [tmp[4, :cs.cout].clone(), tmp[5, :cs.cout].clone()]
 
                 code = best_of(launch, cs.M * cs.coutp, key)
-                cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [cs.inp.t] +
+                a = cs.inp
+                cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [(a.t, a.ld, a.off % a.ld, cs.cinp)] +
                                        ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None)
             if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
-                key = ('dgrad', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld)
+                key = self._dgrad_key(cs)
                 wslice = self._dpack[cs.doff:cs.doff + cs.cinp * cs.k * cs.k * cs.coutp]
 
                 def launch(code, cs=cs):
@@ -510,7 +563,8 @@ class Plan(object):
                          cs.W, cs.coutp, cs.cin, cs.ldraw, cs.inp.ld, cs.k, 0, code, ws.data_ptr(), max_ws, st)
 
                 code = best_of(launch, cs.M * cs.cinp, key)
-                cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld], [cs.raw, wslice])
+                cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld],
+                                         [(cs.raw, cs.ldraw, 0, cs.cout), wslice])
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
@@ -734,24 +788,36 @@ class Plan(object):
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream(device=self.device)
-        side = self.side_stream
-        st2 = side.cuda_stream
         main = torch.cuda.current_stream()
+        side = main if self.serial_backward else self.side_stream
+        st2 = side.cuda_stream
         if self.dgrad_ready is not None:
             main.wait_event(self.dgrad_ready)       # dgrad filter repacks were queued during forward
         else:
-            self._prepare_backward()
+            self._prepare_backward(tune=False)      # the saved conv outputs are live: no timing / verify launches now
             for ind in sorted(self.convs.keys(), reverse=True):   # forward ran without grad bookkeeping: repack now
                 cs = self.convs[ind]
                 if not cs.first:
                     self._repack_dgrad(cs, main)
         out_grads = {}
         training = self.was_training
-        # fresh flat buffer every backward: the returned gradients are views of it (autograd may keep them as .grad)
-        # zeroed: the filter-gradient kernel accumulates channels-last parameters' gradients straight into it
-        flat = torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)
+        # ONE flat gradient buffer per model and device, reused by every backward of every plan (the layout depends on the
+        # model only): the returned gradients are views of it.  Reuse is safe only while nothing else still views the
+        # buffer (optimizer.zero_grad(set_to_none=True) - torch's default - drops the .grad views; a caller that keeps or
+        # accumulates gradients across backwards gets a fresh buffer, the old one stays with the tensors that view it).
+        # Zeroed: the filter-gradient kernel accumulates channels-last parameters' gradients straight into it.
+        ent = self.net._flat_grads.get(self.device)
+        flat = None
+        if ent is not None and ent[0].numel() == self.grad_total and not _storage_shared(ent[0], ent[1], self.net._params()):
+            flat = ent[0]
+            flat.zero_()
+        if flat is None:
+            flat = torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)
+            self.net._flat_grads[self.device] = (flat, _storage_refs(flat))
         flat.record_stream(side)
         self.last_flat_grad = flat
+        if self.reducer is not None:
+            self.reducer.begin(flat)
 
         def gview(prm, channels_last=False):
             off, n, shape = self.grad_layout[id(prm)]

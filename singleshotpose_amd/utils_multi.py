@@ -1,7 +1,8 @@
 """Multi-object decode helpers - host-side mirror of multi_obj_pose_estimation/utils_multi.py.
 
-Everything utils.py offers, plus get_multi_region_boxes (utils_multi.py:266-382) and bbox_iou (:125-156); `nms`
-(:223-241) has no caller on the pose path (valid_multi.py / train_multi.py never invoke it) and is not mirrored.  The per-cell decode (sigmoid, grid offsets, softmax, arg-max) runs in ssp_region_decode_all; the
+Everything utils.py offers, plus get_multi_region_boxes (utils_multi.py:266-382), bbox_iou (:125-156) and `nms`
+(:223-241: no caller on the pose path - valid_multi.py / train_multi.py never invoke it - kept as a small host helper
+because the reference's scripts do `from utils_multi import *`).  The per-cell decode (sigmoid, grid offsets, softmax, arg-max) runs in ssp_region_decode_all; the
 variable-length box lists are assembled on the host from that one device->host copy, with the reference's rules:
 threshold on det_conf (only_objectness) or det_conf*cls_max_conf; a fallback box of `correspondingclass` when no kept
 box has that class; `max_cls_conf` is NOT reset per image.
@@ -37,6 +38,25 @@ def bbox_iou(box1, box2, x1y1x2y2=False):
         return 0.0
     inter = ow * oh
     return inter / ((ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter)
+
+
+def nms(boxes, nms_thresh):
+    """Greedy non-maximum suppression over (x, y, w, h, det_conf, ...) boxes (utils_multi.py:223-241): boxes are visited
+    by descending det_conf; a visited box with det_conf > 0 is kept and zeroes the det_conf (IN PLACE, as the reference
+    does) of every later box whose centre-size IoU with it exceeds `nms_thresh`."""
+    if len(boxes) == 0:
+        return boxes
+    order = np.argsort(np.asarray([1.0 - float(b[4]) for b in boxes], dtype=np.float32), kind='stable')
+    kept = []
+    for pos, i in enumerate(order):
+        cur = boxes[i]
+        if not cur[4] > 0:
+            continue
+        kept.append(cur)
+        for j in order[pos + 1:]:
+            if bbox_iou(cur, boxes[j], x1y1x2y2=False) > nms_thresh:
+                boxes[j][4] = 0
+    return kept
 
 
 def region_rows(output, num_classes, num_keypoints, num_anchors):

@@ -25,15 +25,23 @@ def _worker(rank, world, port, q):
     sizes = [4000, 12, 900, 30000, 64, 64, 70000, 5]
     offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])
     total = int(offs[-1])
-    red = GradReducer(None, world, bucket_bytes=40000 * 4)
+    red = GradReducer(None, world, bucket_bytes=40000 * 4, tail_bytes=0)
     results = []
-    for step in range(2):                                   # a fresh flat buffer every backward
+    flat = torch.empty(total)
+    for step in range(3):                                   # the SAME flat buffer every backward, as Plan.backward reuses it
         g = torch.Generator().manual_seed(100 * step + rank)
-        flat = torch.randn(total, generator=g)
+        flat.copy_(torch.randn(total, generator=g))
         local = flat.clone()
+        red.tail_elems = 71000 if step == 1 else 0          # step 1: the tail rule closes a bucket early
+        red.begin(flat)
         for i in range(len(sizes)):
             red.layer_done(flat, int(offs[i]), int(offs[i + 1]))
-        red.all_reduce()
+        if step < 2:
+            red.all_reduce()
+        else:                                               # a backward that is never joined: the next begin() joins it
+            red.begin(flat)
+            assert not red._pending
+            red.all_reduce()
         # numpy, not tensors: a tensor crosses the queue as a file descriptor that dies with this process
         results.append((local.numpy().copy(), flat.numpy().copy(), list(red.launched)))
     q.put((rank, results))
@@ -53,16 +61,21 @@ def test_gradient_all_reduce_sum_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for step in range(2):
+    for step in range(3):
         expected = out[0][step][0] + out[1][step][0]        # SUM, not mean (reference loss is a batch sum)
         for r in range(world):
             assert np.allclose(out[r][step][1], expected, rtol=0, atol=1e-6)
+        if step == 2:
+            continue                                        # joined by begin(): the bucket list was reset
         buckets = out[0][step][2]
         assert buckets == out[1][step][2]
-        # contiguous, ordered, covering the whole buffer; every bucket but the last reaches the size threshold
+        # contiguous, ordered, covering the whole buffer
         assert buckets[0][0] == 0 and buckets[-1][1] == expected.size
         assert all(b[1] == c[0] for b, c in zip(buckets, buckets[1:]))
-        assert all(b[1] - b[0] >= 40000 for b in buckets[:-1]) and len(buckets) >= 2
+        if step == 0:     # size rule only: every bucket but the last reaches the threshold
+            assert all(b[1] - b[0] >= 40000 for b in buckets[:-1]) and len(buckets) == 2
+        else:             # tail rule: the first bucket closes as soon as <= 71000 elements are still to come
+            assert buckets == [(0, 34912), (34912, 105040), (105040, 105048)], buckets
 
 
 def test_reducer_is_inert_for_one_rank():

@@ -52,16 +52,17 @@ def test_rccl_bucketed_all_reduce_world1():
 # build stages device tensors through the host - while everything else is the product path: Darknet on the HIP plan,
 # Plan.backward notifying the GradReducer from the filter-gradient stream, bucketed asynchronous all-reduce(SUM) of
 # the flat gradient buffer, the fused optimizer consuming the reduced buffer with global-batch lr / decay.
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, backend='gloo'):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs on this driver
+    torch.cuda.set_device(rank if backend == 'nccl' else 0)       # RCCL: one GPU per rank; gloo: both ranks share cuda:0
     from oracle.darknet_ref import seeded_state
     from singleshotpose_amd.darknet import Darknet
     from singleshotpose_amd.dist import GradReducer, init_distributed
     from singleshotpose_amd.optim import SGD
     from singleshotpose_amd.region_loss import RegionLoss
-    init_distributed('gloo')
+    init_distributed(backend)
     per_rank = 2
     global_batch = per_rank * world
     cfg = os.path.join(GOLD, 'tiny-pose.cfg')
@@ -79,7 +80,7 @@ def _dp_worker(rank, world, port, q):
 
     # (a) one bucket, launched by all_reduce(): the local gradient is complete and can be read before the exchange
     model = build()
-    red = GradReducer(model, world, bucket_bytes=1 << 40)
+    red = GradReducer(model, world, bucket_bytes=1 << 40, tail_bytes=0)
     crit(model(x), tgt, 20).backward()
     torch.cuda.synchronize()
     plan = list(model._plans.values())[0]
@@ -130,12 +131,23 @@ def _dp_worker(rank, world, port, q):
 
 
 def test_data_parallel_two_ranks_model_level():
+    _run_two_ranks('gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: fewer than 2 GPUs visible")
+def test_data_parallel_two_ranks_rccl():
+    """The same model-level check under RCCL ("nccl" backend) over xGMI, one GPU per rank - runs wherever two GPUs are
+    visible (the driver's multi-GPU node); the single-GPU test box runs the gloo form above."""
+    _run_two_ranks('nccl')
+
+
+def _run_two_ranks(backend):
     import torch.multiprocessing as mp
     world = 2
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))

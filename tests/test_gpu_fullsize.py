@@ -127,6 +127,60 @@ def test_multi_object_full_trunk_train_step():
     _assert_exact(res)
 
 
+# Multi-scale training: dataset.py:66-90 draws H = W from {224, 256, ..., 832} (7..26 cells of 32
+# pixels) every 10 batches once `seen` passes 10 epochs, and cfg/yolo-pose.cfg:23-24 tests at 672 x 672.  The FULL network
+# at the smallest, a mid and the largest training resolution at the cfg's own batch (8), plus one non-416 shape at the
+# metric's batch (64): the same decision-frozen step check and the same bars as the 416 x 416 headline test - tuned plans
+# on (these shapes pick other tiles / splits / hybrid launches / XCD orders than 416 does: 7 x 7 ... 26 x 26 head grids).
+MULTISCALE = [(224, 8), (608, 8), (832, 8), (352, 64)]
+
+
+@pytest.mark.parametrize("size,B", MULTISCALE)
+def test_multiscale_full_network_train_step(size, B):
+    from oracle.darknet_ref import seeded_state
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    assert os.environ.get('SSP_AUTOTUNE', '1') != '0'
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 100 + size))
+    model = model.cuda()
+    rs = np.random.RandomState(size)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, size, size)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [1 + (i % 3 == 2) for i in range(B)]))
+    n_rej = len(engine.TUNE_REJECTED)
+    res = check_train_step(model, RegionLoss(), x, tgt, 20)
+    _report('yolo-pose B=%d %dx%d' % (B, size, size), res)
+    assert tuple(model._plans.keys())[0][:3] == (B, size, size)
+    assert any(f or d for _, f, d in res['plans']), "the autotuner picked no plan: nothing tuned was exercised"
+    assert len(engine.TUNE_REJECTED) == n_rej, engine.TUNE_REJECTED[n_rej:]
+    _assert_step(res)
+
+
+def test_multiscale_schedule_one_model_many_shapes():
+    """What train.py does after epoch 10: ONE model, a new resolution every few batches, shapes revisited.  Every visit
+    of every shape (first visit = plan build + autotune + verify-after-tune, second visit = cached plan) against the
+    oracle with the same bars; BatchNorm running statistics carry over from visit to visit as in the reference."""
+    from oracle.darknet_ref import seeded_state
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 77))
+    model = model.cuda()
+    crit = RegionLoss()
+    rs = np.random.RandomState(77)
+    B = 4
+    for visit, size in enumerate((480, 288, 480, 736, 288)):
+        x = torch.from_numpy(rs.uniform(0, 1, (B, 3, size, size)).astype(np.float32))
+        tgt = torch.from_numpy(make_targets(rs, B, [1] * B))
+        res = check_train_step(model, crit, x, tgt, 20)
+        _report('visit %d: yolo-pose B=%d %dx%d' % (visit, B, size, size), res)
+        _assert_step(res)
+    assert sorted(k[1] for k in model._plans.keys()) == [288, 480, 736]
+
+
 def test_tuned_plans_every_candidate_matches_default_on_bench_shapes():
     """Every plan code the autotuner may hand to a launch (engine.Plan._autotune candidates), on two of the benchmark's
     launch shapes (64 x 13 x 13, 1024 -> 1024 and 64 x 26 x 26, 256 -> 512): identical results to the default plan

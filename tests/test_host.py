@@ -231,13 +231,33 @@ sys.path.insert(0, os.path.join(r"%s", "dropin", "multi_obj_pose_estimation"))
 from darknet_multi import Darknet as DM      # train_multi.py
 from region_loss_multi import RegionLoss as RLM
 import utils_multi
-for n in "bbox_iou get_multi_region_boxes corner_confidences pnp get_3D_corners".split():
+for n in "bbox_iou nms get_multi_region_boxes corner_confidences pnp get_3D_corners".split():
     assert callable(getattr(utils_multi, n)), n
 print("ok")
 ''' % (os.path.join(root, 'cfg', 'yolo-pose.cfg'), os.path.join(root, 'cfg', 'yolo-pose.cfg'), root)
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, 'dropin')]))
     out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+def test_bbox_iou_and_nms_match_the_reference():
+    """utils_multi.bbox_iou / nms (multi_obj_pose_estimation/utils_multi.py:125-156,223-241) against outputs of the
+    reference's own functions (oracle/gen_golden.py --nms): kept boxes in order, and the in-place det_conf zeroing."""
+    import numpy as np
+    from helpers import gold
+    from singleshotpose_amd.utils_multi import bbox_iou, nms
+    g = gold('nms.npz')
+    for case in range(3):
+        b = g['in_%d' % case]
+        iou = np.array([[bbox_iou(x, y, x1y1x2y2=False) for y in b] for x in b])
+        np.testing.assert_allclose(iou, g['iou_%d' % case], rtol=1e-12, atol=1e-15)
+        iou2 = np.array([[bbox_iou(np.sort(x[:4]), np.sort(y[:4]), x1y1x2y2=True) for y in b] for x in b])
+        np.testing.assert_allclose(iou2, g['iou_xyxy_%d' % case], rtol=1e-12, atol=1e-15)
+        boxes = [list(map(float, r)) for r in b]
+        kept = nms(boxes, 0.4)
+        assert np.array_equal(np.array(kept, dtype=np.float64).reshape(len(kept), -1), g['kept_%d' % case])
+        assert np.array_equal(np.array(boxes, dtype=np.float64), g['after_%d' % case])
+    assert nms([], 0.4) == []
 
 
 def test_tune_cache_round_trip(tmp_path, monkeypatch):

@@ -1,44 +1,60 @@
 #!/usr/bin/env python
-"""One-off parity sweep of the FULL yolo-pose.cfg over multi-scale training resolutions (dataset.py:66-90: 224..832 in
-steps of 32) against the CPU oracle: train-mode forward + backward, output and every conv / BN gradient norm.
-Exercises the per-shape plans the autotuner picks (hybrid launches, deep split-K, XCD-ordered wgrad, folded taps)."""
-import os, sys, time
-import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from helpers import clone_state, load_state_into, rel_err
-from oracle.darknet_ref import forward_ref, seeded_state
-from singleshotpose_amd.darknet import Darknet
+"""Parity sweep of the FULL yolo-pose.cfg over the multi-scale training resolutions (dataset.py:66-90: 224..832 in steps
+of 32) with ONE model, as train.py visits them: every shape's training step through oracle/step_check.py (decision-frozen
+oracle backward) with the bars of tests/test_gpu_fullsize.py - head / loss / running statistics / every conv launch /
+every parameter gradient <= 1e-4 (first layer's filter gradient 5e-4 against its float64 re-evaluation).  Exercises the
+per-shape plans the autotuner picks (hybrid launches, deep split-K, XCD-ordered wgrad, folded taps).
 
-sizes = [int(s) for s in sys.argv[1].split(',')] if len(sys.argv) > 1 else [224, 352, 480, 608]
+  python tools/multiscale_check.py [sizes, comma separated | all] [batch] [json out]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import load_state_into, make_targets  # noqa: E402
+from oracle.darknet_ref import seeded_state  # noqa: E402
+from oracle.step_check import check_train_step, summarize  # noqa: E402
+from singleshotpose_amd import engine  # noqa: E402
+from singleshotpose_amd.darknet import Darknet  # noqa: E402
+from singleshotpose_amd.region_loss import RegionLoss  # noqa: E402
+
+arg = sys.argv[1] if len(sys.argv) > 1 else '224,352,480,608,832'
+sizes = list(range(224, 833, 32)) if arg == 'all' else [int(s) for s in arg.split(',')]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+out_path = sys.argv[3] if len(sys.argv) > 3 else None
 model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
-state = seeded_state(model.blocks, 3)
-load_state_into(model, model.blocks, state)
-model = model.cuda().train()
-worst = 0.0
+load_state_into(model, model.blocks, seeded_state(model.blocks, 3))
+model = model.cuda()
+crit = RegionLoss()
+rec, ok_all = [], True
 for s in sizes:
     rs = np.random.RandomState(s)
     x = torch.from_numpy(rs.uniform(0, 1, (B, 3, s, s)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [1] * B))
     t0 = time.time()
-    model.zero_grad()
-    out = model(x.cuda())
-    st = clone_state(state, requires_grad=True)
-    y = forward_ref(model.blocks, st, x, training=True)
-    probe = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
-    (out * probe.cuda()).sum().backward()
-    (y * probe).sum().backward()
-    e_out = rel_err(out.detach().cpu().numpy(), y.detach().numpy())
-    errs = []
-    for ind, e in enumerate(st):
-        if e is not None:
-            g = model.models[ind][0].weight.grad.cpu().numpy()
-            r = e['weight'].grad.numpy()
-            errs.append(abs(np.linalg.norm(g) / np.linalg.norm(r) - 1))
-    worst = max(worst, e_out, max(errs))
-    print('size %3d B=%d: out rel err %.2e, conv-grad norm rel err max %.2e mean %.2e  (%.1f s)' %
-          (s, B, e_out, max(errs), float(np.mean(errs)), time.time() - t0))
-    # BN running statistics were updated by both: reset the module's from the oracle's copy for the next size
-    load_state_into(model, model.blocks, state)
-print('worst', worst)
-sys.exit(0 if worst < 2e-2 else 1)
+    r = check_train_step(model, crit, x, tgt, 20)
+    worst = max(r['grad_by_param'].items(), key=lambda kv: kv[1])
+    ok = (all(r[k] < 1e-4 for k in ('head', 'loss', 'running', 'conv', 'grad_out')) and
+          all(e < (5e-4 if n == '0.weight' else 1e-4) for n, e in r['grad_by_param'].items()))
+    ok_all = ok_all and ok
+    print('size %3d B=%d: %s | worst grad %s %.2e | %s (%.1f s)' % (s, B, summarize(r), worst[0], worst[1],
+                                                                  'ok' if ok else 'FAIL', time.time() - t0), flush=True)
+    rec.append(dict(size=s, batch=B, ok=ok, worst_grad_param=worst[0],
+                    tuned_plans=sum(1 for _, f, d in r['plans'] if f or d),
+                    **{k: float('%.3g' % r[k]) for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad')}))
+print('tune rejections', engine.TUNE_REJECTED)
+if out_path:
+    with open(out_path, 'w') as f:
+        json.dump(dict(what="cfg/yolo-pose.cfg train step per multi-scale resolution vs oracle/step_check.py "
+                            "(decision-frozen backward), one model visiting the shapes in order",
+                       bars=dict(head=1e-4, loss=1e-4, running=1e-4, conv=1e-4, grad_out=1e-4, grad=1e-4,
+                                 grad_first_filter=5e-4),
+                       tune_rejected=[list(map(str, t)) for t in engine.TUNE_REJECTED], shapes=rec), f, indent=1)
+sys.exit(0 if ok_all else 1)
