@@ -555,6 +555,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       case 3: if (bk >= 16) return launch_cfg<256, 128, 4, 2, 16>(a, stream); break;
       case 4: if (bk == 32) return launch_cfg<128, 128, 2, 2, 32, 1>(a, stream); break;
       case 5: if (bk == 32) return launch_cfg<128, 128, 2, 2, 32, 2>(a, stream); break;
+#ifdef SSP_PROBES   // timing probes that skip loads / the epilogue: WRONG RESULTS on purpose, never in the shipped library (make PROBES=1)
       case 10: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1>(a, stream); break;            // no loads
       case 14: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16>(a, stream); break;  // MFMA only
       case 17: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 1 | 4 | 8 | 16 | 32>(a, stream); break;  // MFMA only, no epilogue
@@ -563,6 +564,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
       case 42: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 256>(a, stream); break;   // MFMA only + LDS-read probe
       case 43: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 29 | 64 | 128 | 256>(a, stream); break;
       case 18: if (bk >= 16) return launch_cfg<128, 128, 2, 2, 16, 32>(a, stream); break;   // full loop, no epilogue
+#endif
       case 21: if (bk >= 16) return launch_cfg<128, 64, 2, 2, 16>(a, stream); break;
       case 22: if (bk >= 16) return launch_cfg<64, 64, 2, 2, 16>(a, stream); break;
       default: break;

@@ -25,7 +25,7 @@ struct ConvArgs {
   int ws_row0, ws_rows;
   int col_major;       // tile order inside a launch: tile_m fastest (workgroups resident on one XCD share a filter slab)
   SspFastDiv divW, divH;   // m -> (x, y) of a tile row without run-time integer division
-  int probe;           // timing probes (igemm_variant 60: skip the epilogue; results are wrong on purpose)
+  int probe;           // 2: generic (predicated) epilogue everywhere (A/B switch, same results); 1: SSP_PROBES builds only
   // Data-gradient launches only: BatchNorm-backward reductions of the block that PRODUCED the activation whose gradient
   // this launch writes (out = g = dL/d leaky(BN(raw))).  With bn_partial set, the finishing pass (tile epilogue or
   // splitk_reduce_kernel) also reads that block's raw conv output at the tile's positions and leaves, per M tile and

@@ -42,7 +42,14 @@ class _RegionLossFn(torch.autograd.Function):
         stats = torch.empty(8, dtype=torch.float32, device=out.device)
         anchors = None
         if mod._multi:
-            anchors = torch.tensor([float(a) for a in mod.anchors], dtype=torch.float32, device=out.device)
+            # uploaded once per anchor set: a torch.tensor(list, device=...) per call is a pageable host->device copy, which
+            # blocks the host until the work queued before it has drained
+            akey = (tuple(float(a) for a in mod.anchors), str(out.device))
+            cache = mod.__dict__.setdefault('_anchor_cache', {})
+            anchors = cache.get(akey)
+            if anchors is None:
+                cache.clear()
+                anchors = cache[akey] = torch.tensor(akey[0], dtype=torch.float32, device=out.device)
             step = len(mod.anchors) // nA
         else:
             step = 0
@@ -53,6 +60,10 @@ class _RegionLossFn(torch.autograd.Function):
                   float(mod.noobject_scale), float(mod.object_scale), float(mod.coord_scale), float(mod.class_scale),
                   float(mod.thresh), conf_on, 1 if mod._multi else 0,
                   anchors.data_ptr() if anchors is not None else None, step, st)
+        for slot in mod.__dict__.get('_pin_ring', {}).values():
+            rel = slot.pop('release', None)
+            if rel is not None:
+                rel[0].record(rel[1])       # this slot's pinned and device label buffers are free once the kernel has run
         ctx.save_for_backward(grad)
         mod._last_stats = stats
         return stats[4].clone()
@@ -86,24 +97,37 @@ class _RegionLossBase(nn.Module):
     def _upload(self, host_tensor, device):
         """Host labels -> device without stalling the host: a `.to(device)` from pageable memory blocks the Python
         thread until the forward pass queued before it has drained (the reference pays exactly that, train.py:83-97).
-        The labels are staged through a small ring of pinned buffers and copied asynchronously in stream order."""
-        key = (tuple(host_tensor.shape), host_tensor.dtype)
+        The labels are staged through a ring of 4 pinned host buffers, each paired with its own device buffer and event,
+        all created once per (shape, dtype, device): a call is one host memcpy into the pinned slot, one asynchronous
+        copy in stream order, one event record - no allocation (host, device or event) after the first lap of the ring.
+        `upload_host_us` keeps the host time of the last calls (tools/label_upload_probe.py, tests/test_gpu_head.py)."""
+        import time
+        t0 = time.perf_counter()
+        key = (tuple(host_tensor.shape), host_tensor.dtype, str(device))
         ring = self.__dict__.setdefault('_pin_ring', {})
         slot = ring.get(key)
         if slot is None:
-            slot = {'bufs': [torch.empty(host_tensor.shape, dtype=host_tensor.dtype).pin_memory() for _ in range(4)],
-                    'events': [None] * 4, 'next': 0}
+            n = 4
+            slot = {'pin': [torch.empty(host_tensor.shape, dtype=host_tensor.dtype).pin_memory() for _ in range(n)],
+                    'dev': [torch.empty(host_tensor.shape, dtype=host_tensor.dtype, device=device) for _ in range(n)],
+                    'events': [torch.cuda.Event() for _ in range(n)], 'used': [False] * n, 'next': 0}
             ring[key] = slot
         i = slot['next']
-        slot['next'] = (i + 1) % 4
-        if slot['events'][i] is not None:
-            slot['events'][i].synchronize()      # the copy that last used this buffer finished long ago
-        slot['bufs'][i].copy_(host_tensor)
-        dev = slot['bufs'][i].to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        slot['events'][i] = ev
-        return dev
+        slot['next'] = (i + 1) % len(slot['pin'])
+        stream = torch.cuda.current_stream(device)
+        if slot['used'][i]:
+            # the copy that last read this pinned buffer (and the kernel that last read its device twin) were queued 4
+            # calls ago: normally long finished, so this returns at once; a caller hopping streams is ordered by the wait
+            slot['events'][i].synchronize()
+        slot['pin'][i].copy_(host_tensor)
+        slot['dev'][i].copy_(slot['pin'][i], non_blocking=True)
+        slot['used'][i] = True
+        slot['release'] = (slot['events'][i], stream)      # recorded by forward() after the kernel that reads the labels
+        hist = self.__dict__.setdefault('upload_host_us', [])
+        hist.append((time.perf_counter() - t0) * 1e6)
+        if len(hist) > 4096:
+            del hist[:2048]
+        return slot['dev'][i]
 
     def last_stats(self):
         """Device tensor [loss_x, loss_y, loss_conf, loss_cls, total, nGT, nCorrect, nProposals] of the last call."""

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Host time of RegionLoss.forward with HOST float64 labels (what train.py:83-97 hands over), call by call.
+
+Round 2 committed one 8.3 ms average for this call (profiles/r02_infer.json) next to 84-95 us on two other visits: this
+probe times every call on the host (perf_counter around the call, no synchronize inside the loop, a synchronize between
+rounds), 10 rounds x 500 calls, and reports per round the median / p99 / max of (a) the whole call and (b) the label
+upload alone (RegionLoss.upload_host_us), plus the indices of calls above 0.5 ms - so an intermittent stall shows where it
+sits (first lap of the pinned ring, a ring wrap, the allocator, ...).  Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from singleshotpose_amd.region_loss import RegionLoss, RegionLossMulti
+    dev = torch.device('cuda', 0)
+    rounds, calls = 10, 500
+    out = {}
+    for name, crit, ch, nlab in (('single', RegionLoss(), 20, 1),
+                                 ('multi', RegionLossMulti(anchors=[1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018,
+                                                                    3.9910, 3.4879, 5.8851]), 160, 8)):
+        crit.verbose = False
+        head = torch.randn(64, ch, 13, 13, device=dev, requires_grad=True)
+        g = torch.Generator().manual_seed(0)
+        t = torch.zeros(64, 50, 21, dtype=torch.float64)
+        for k in range(nlab):
+            t[:, k, 0] = float(k % 13)
+            t[:, k, 1:19] = torch.rand(64, 18, generator=g, dtype=torch.float64) * 0.5 + 0.25
+            t[:, k, 19:21] = 0.2
+        tgt = t.view(64, -1)
+        rec = []
+        for r in range(rounds):
+            torch.cuda.synchronize()
+            crit.upload_host_us = []
+            ts = np.empty(calls)
+            for i in range(calls):
+                t0 = time.perf_counter()
+                crit(head, tgt.clone() if i % 7 == 0 else tgt, 20)      # a fresh label tensor now and then, as a DataLoader yields
+                ts[i] = (time.perf_counter() - t0) * 1e6
+            torch.cuda.synchronize()
+            up = np.asarray(crit.upload_host_us[-calls:])
+            rec.append(dict(call_us=dict(median=round(float(np.median(ts)), 1), p99=round(float(np.percentile(ts, 99)), 1),
+                                         max=round(float(ts.max()), 1)),
+                            upload_us=dict(median=round(float(np.median(up)), 1), p99=round(float(np.percentile(up, 99)), 1),
+                                           max=round(float(up.max()), 1)),
+                            slow_calls=[(int(i), round(float(ts[i]), 1)) for i in np.nonzero(ts > 500.0)[0][:8]]))
+        out[name] = rec
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
