@@ -21,7 +21,7 @@ struct WgradArgs {
   float* dw;
   int H, W, Cin, Cout, lddy, ldx, R, M;
   int ntile_co, ntile_ci, nsplit, chunk_m;
-  int xcd_order;  // XCD-aware workgroup order (see the kernel)
+  int xcd_order;  // XCD-aware workgroup order (see the kernel): 1 = all tiles of a pixel range on one XCD, 2 = per (range, cout tile)
   int no_store;   // 2: generic epilogue (A/B switch, same results); 1: SSP_PROBES builds only - skip the atomic epilogue
   int fold;   // filter taps per cin tile: 1, or BNI / Cin when Cin < BNI (thin layers: two taps of 32 cins share a tile)
 };
@@ -78,7 +78,19 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   // on XCD s % 8, consecutively in its dispatch order, so they stream those rows through that L2 together (the plain
   // order spreads each range over all XCDs and over time: every tap re-fetches the operands from HBM).
   int split, bid;
-  if (p.xcd_order) {
+  if (p.xcd_order == 2) {
+    // Layers with more tiles than an XCD holds at once (the 13 x 13 layers: 144 - 360 tiles): the unit that shares
+    // operands is (pixel range s, cout tile c) - its taps x cin tiles (36 - 90 workgroups) all read the same
+    // [range][BMO] dY slab, and the 9 taps of a cin tile the same X rows.  Units are dealt to the XCDs round robin and a
+    // unit's workgroups are consecutive in its XCD's dispatch order, so the slab streams through ONE L2 once instead of
+    // being fetched over the fabric by workgroups scattered over all eight (plain order: 2.4 MB per workgroup).
+    const int Gu = tap_groups * p.ntile_ci;
+    const int x = blockIdx.x % 8, q = blockIdx.x / 8;
+    const int u = x + 8 * (q / Gu);
+    if (u >= p.nsplit * p.ntile_co) return;      // grid padded to a multiple of 8 units
+    split = u / p.ntile_co;
+    bid = (u % p.ntile_co) * Gu + q % Gu;
+  } else if (p.xcd_order) {
     const int G = tap_groups * p.ntile_ci * p.ntile_co;
     const int x = blockIdx.x % 8, q = blockIdx.x / 8;
     split = x + 8 * (q / G);
@@ -373,7 +385,9 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   // from one wave up to five; only when no split gets there the best-filling one wins.  >= 8 chunks per workgroup.
   const int variant = ssp_option(SSP_OPT_WGRAD_VARIANT);
   const int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);
-  int64_t lo = ((int64_t)slots + tiles - 1) / tiles, hi = (5 * (int64_t)slots) / tiles;
+  // (order 2, below: the split also has to deal its units evenly to the 8 XCDs - a wider search range)
+  const bool order2 = !FOLD && variant != 10 && variant != 12 && tiles > 64 && max_split >= 16 && a.R * a.R * a.ntile_ci <= 128;
+  int64_t lo = ((int64_t)slots + tiles - 1) / tiles, hi = ((order2 ? 8 : 5) * (int64_t)slots) / tiles;
   if (tiles >= (int64_t)(0.93 * slots)) lo = 1;        // the tiles alone (almost) fill a wave
   if (variant == 4) lo = (2 * (int64_t)slots + tiles - 1) / tiles;   // experiment: at least two waves (the old rule)
   if (lo < 1) lo = 1;
@@ -383,6 +397,8 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   // XCD-aware order (see the kernel) when the workgroups of one pixel range fit one XCD's resident set (64); the split
   // is then a multiple of 8 so that every XCD gets the same number of pixel ranges
   a.xcd_order = (variant != 10 && tiles <= 64 && max_split >= 16) ? 1 : 0;
+  // More tiles than that (the 13 x 13 layers): units of (pixel range, cout tile) dealt to the XCDs (order 2); the split is
+  // chosen so that the units divide evenly over the 8 XCDs (or are many enough for the remainder not to matter)
   const int64_t step = a.xcd_order ? 8 : 1;
   if (a.xcd_order) {
     lo = (lo + 7) / 8 * 8;
@@ -394,16 +410,27 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   double best = -1.0;
   for (int64_t sp = lo; sp <= hi; sp += (a.xcd_order ? step : 1)) {
     const double waves = (double)(tiles * sp) / slots;
-    const double eff = waves / (double)((tiles * sp + slots - 1) / slots);
+    double eff = waves / (double)((tiles * sp + slots - 1) / slots);
+    if (order2) {      // XCDs holding one unit more than the others finish last
+      const int64_t units = sp * a.ntile_co;
+      eff *= ((double)units / 8.0) / (double)((units + 7) / 8);
+    }
     if (eff > best + 1e-3) { best = eff; nsplit = sp; }
     if (eff >= 0.93) break;
   }
+  const int forced_split = ssp_option(SSP_OPT_WGRAD_SPLIT);      // experiments: tools/conv_bench.py --opt wgrad_split=N
+  if (forced_split > 0 && forced_split <= max_split && !(a.xcd_order == 1 && forced_split % 8)) nsplit = forced_split;
   int64_t chunk = (a.M + nsplit - 1) / nsplit;
   chunk = (chunk + RA - 1) / RA * RA;
   nsplit = (a.M + chunk - 1) / chunk;
   a.nsplit = (int)nsplit;
   a.chunk_m = (int)chunk;
-  const int64_t nwg = a.xcd_order ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
+  int64_t nwg = a.xcd_order ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
+  if (order2) {
+    a.xcd_order = 2;
+    const int64_t units = nsplit * a.ntile_co, gu = (int64_t)ssp_cdiv(a.R * a.R, a.fold) * a.ntile_ci;
+    nwg = 8 * gu * ((units + 7) / 8);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_wgrad_dma");
   return SSP_OK;

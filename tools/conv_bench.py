@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--opt', default='', help='name=value,... passed to ssp_set_option')
     ap.add_argument('--wvariants', default='', help='comma list of wgrad_variant values to loop over')
     ap.add_argument('--variants', default='', help='comma list: run every case once per igemm_variant value')
+    ap.add_argument('--sweep', default='', help='option sets "name=value,...;name=value,..." (- = defaults): every case once per set, '
+                                                'in one process (options of the previous set are reset to 0)')
     args = ap.parse_args()
     for kv in filter(None, args.opt.split(',')):
         k, v = kv.split('=')
@@ -36,6 +38,19 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     B = args.B
     variants = [int(v) for v in args.variants.split(',')] if args.variants else [None]
+    if args.sweep:
+        touched = set()
+        for cfg in args.sweep.split(';'):
+            for name in touched:
+                _lib.call('ssp_set_option', name.encode(), 1 if name == 'igemm_xcd' else 0)
+            touched = set()
+            for kv in filter(None, (cfg if cfg != '-' else '').split(',')):
+                k, v = kv.split('=')
+                _lib.call('ssp_set_option', k.encode(), int(v))
+                touched.add(k)
+            print('SWEEP', cfg, flush=True)
+            run_cases(args, dev, st, B)
+        return
     if args.wvariants:
         for wv in [int(v) for v in args.wvariants.split(',')]:
             _lib.call('ssp_set_option', b'wgrad_variant', wv)
