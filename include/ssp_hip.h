@@ -42,7 +42,13 @@ int ssp_set_option(const char* name, int value);
  *   the latency form for grids of about one workgroup per CU: seven K chunks in flight, one workgroup per CU;
  *   tail 0 or 2..9 = hybrid launch: whole resident waves un-split, the last partial wave's tiles split `tail` ways);
  * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
- * models) may run different plans concurrently.  The same code must be passed to the two queries. */
+ * models) may run different plans concurrently.  The same code must be passed to the two queries.
+ *   9000000 + tile_rows*100 + 10 + ring_slots = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout > 64
+ *   and % 4 == 0; conv_wino.hip): same result to ~1e-6 of its range with 16/36 of the multiplies.  `wt` must then be the
+ *   TRANSFORMED filter from ssp_wino_filter_transform (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the workspace
+ *   (ssp_conv_workspace_floats: 16 * tiles * (Cin + Cout) floats) is mandatory; a Winograd code on a shape it does not
+ *   fit is an error, not a fallback (the filter operand differs).  Valid for ssp_conv_fwd, ssp_conv_fwd_affine,
+ *   ssp_conv_dgrad and ssp_conv_dgrad_bnbwd. */
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
                  int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int plan, float* workspace,
                  int64_t workspace_floats, void* stream);
@@ -53,6 +59,10 @@ int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const floa
                         float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R, int plan,
                         float* workspace, int64_t workspace_floats, void* stream);
 int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int plan);
+/* U[xi][row][k] = (G g G^T)[xi], xi = 0..15, of the 3x3 filters g[tap] = w9[row][tap][k] (rows x 9 x K floats, K % 4 == 0):
+ * the filter operand of a Winograd plan.  rows = Cout, K = Cin for the forward layout; rows = Cin_dx, K = Cout_dy for the
+ * data-gradient layout.  U: 16 * rows * K floats. */
+int ssp_wino_filter_transform(const float* w9, float* U, int rows, int K, void* stream);
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan);
 
 /* data gradient (autograd of nn.Conv2d, train.py:103): dx[p][ci] (+)= sum dy[p - tap][co] * w[co][ci][tap];

@@ -30,6 +30,7 @@ _SIGS = {
     "ssp_conv_fwd_affine": [P, P, P, P, P, F, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_stats_tile_m": [I, I, I, I, I, I, I],
     "ssp_conv_workspace_floats": [I, I, I, I, I, I, I],
+    "ssp_wino_filter_transform": [P, P, I, I, P],
     "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_dgrad_bnbwd": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, I, P, P, P, P, F, P, I, P],
     "ssp_bn_act_bwd_partials": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, I, P, I, I, P, P, P, P, P],

@@ -41,6 +41,11 @@ struct ConvArgs {
                        // must be zero on entry); fewer tiles: one plain store per (tile, channel), deterministic
   int bn_ld;
   float bn_slope;
+  // Batched GEMM (the 16 transform positions of a Winograd layer, conv_wino.hip): gridDim.y problems that share the shape;
+  // problem b reads in + b * batch_in, wt + b * batch_wt and writes out + b * batch_out (floats).  batch = 0: one problem.
+  // Plain stores only (no statistics, bias, split-K or fused reductions in a batched launch).
+  int batch;
+  int64_t batch_in, batch_wt, batch_out;
 };
 
 __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
@@ -59,7 +64,9 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `smem` must be free (all LDS traffic of the K loop retired).
 template <int BM, int BN, int WM, int WN, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                               int m0, int n0, int tile_m, int split, int tid, bool partial) {
+                                               int m0, int n0, int tile_m, int split, int tid, bool partial,
+                                               int64_t out_off = 0) {
+  float* const outp = p.out + out_off;      // batched launches: this problem's output plane
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -139,7 +146,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
           float v = acc[i][j][r] * esc + bias;
           v = v > 0.f ? v : v * p.act_slope;
           if (m < p.M && n_ok) {
-            float* o = p.out + (int64_t)m * p.ldout + n;
+            float* o = outp + (int64_t)m * p.ldout + n;
             if constexpr (ACCUM) v += *o;
             *o = v;
             cnt += 1.f;
@@ -204,7 +211,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& p, f32x16 (&acc)[
     constexpr bool BNB = decltype(bnb_tag)::value;
     constexpr bool IDENT = decltype(ident_tag)::value;     // no bias, no per-channel scale, no activation
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + (int64_t)m0 * p.ldout), 0, BM * p.ldout * 4, 0x00020000);
+        (void*)(outp + (int64_t)m0 * p.ldout), 0, BM * p.ldout * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = rs_o;
     if constexpr (BNB)
       rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn_raw + (int64_t)m0 * p.bn_ld), 0, BM * p.bn_ld * 4, 0x00020000);

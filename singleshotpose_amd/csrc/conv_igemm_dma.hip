@@ -128,12 +128,14 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
   const int it_begin = split * it_ps;
   const int niter = min(niter_all, it_begin + it_ps) - it_begin;
 
-  // ---- buffer descriptors: A starts (W+1) pixels before the tile so every tap offset is non-negative ----
-  const int halo = p.W + 1;
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + ((int64_t)m0 - halo) * p.ldin), 0, (int)SSP_OOB, 0x00020000);
+  // ---- buffer descriptors: A starts (W+1) pixels before the tile so every tap offset is non-negative (a 1x1 filter has
+  // no negative tap: no halo - the batched GEMMs of conv_wino.hip run this kernel with W = their row count) ----
+  const int halo = (p.R == 1) ? 0 : p.W + 1;
+  const int64_t bz = (p.batch > 1) ? (int64_t)blockIdx.y : 0;      // batched launch: problem index (scalar)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in + bz * p.batch_in + ((int64_t)m0 - halo) * p.ldin), 0, (int)SSP_OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + (int64_t)n0 * K), 0, (int)SSP_OOB, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt + bz * p.batch_wt + (int64_t)n0 * K), 0, (int)SSP_OOB, 0x00020000);
 
   // ---- loader lanes: a wave-instruction covers 16 tile rows; lane -> (row = lane>>2, physical chunk = lane&3) ----
   const int lrow = lane >> 2, lch = lane & 3;
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
 #ifdef SSP_PROBES   // timing probe (igemm_variant 60): skip the epilogue - wrong results on purpose, probe builds only (make PROBES=1)
   if (p.probe == 1 && acc[0][0][0] != 12345.678f) return;
 #endif
-  igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid, partial);
+  igemm_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, tile_m, split, tid, partial, bz * p.batch_out);
 #endif
 }
 
@@ -361,7 +363,7 @@ static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
       nwg = (unsigned)(a.tail_begin + (a.ntile_m - tm1) * a.ntile_n * a.tail_ks);
     }
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL(kern, dim3(nwg, a.batch > 1 ? a.batch : 1), dim3(256), lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_igemm_dma");
   return SSP_OK;
 }

@@ -386,7 +386,10 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   const int variant = ssp_option(SSP_OPT_WGRAD_VARIANT);
   const int64_t max_split = (a.M + RA * 8 - 1) / (RA * 8);
   // (order 2, below: the split also has to deal its units evenly to the 8 XCDs - a wider search range)
-  const bool order2 = !FOLD && variant != 10 && variant != 12 && tiles > 64 && max_split >= 16 && a.R * a.R * a.ntile_ci <= 128;
+  // measured (profiles/r03_convbench_wgrad.txt): no gain over the plain order on layers 18 - 29 (117.6 / 124.3 / 131.3 TF against
+  // 120.9 / 125.1 / 129.9): their operands (44 MB each) live in the 256 MB Infinity Cache and the kernel is not bound by
+  // that traffic - kept as an experiment switch (wgrad_variant 20), off by default
+  const bool order2 = variant == 20 && !FOLD && tiles > 64 && max_split >= 16 && a.R * a.R * a.ntile_ci <= 128;
   int64_t lo = ((int64_t)slots + tiles - 1) / tiles, hi = ((order2 ? 8 : 5) * (int64_t)slots) / tiles;
   if (tiles >= (int64_t)(0.93 * slots)) lo = 1;        // the tiles alone (almost) fill a wave
   if (variant == 4) lo = (2 * (int64_t)slots + tiles - 1) / tiles;   // experiment: at least two waves (the old rule)

@@ -14,6 +14,8 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
                           int64_t ws_floats, int plan, int prof_kind, hipStream_t stream,
                           const float* escale = nullptr, float act_slope = 1.f, const SspBnBwdFuse* bnb = nullptr);
+int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout);
+int ssp_wino_filter_launch(const float* w, float* U, int rows, int K, hipStream_t stream);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
@@ -187,7 +189,11 @@ int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int pla
   return ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan);
 }
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  if (plan >= 9000000 && plan < 10000000) return ssp_wino_ws_floats(B, H, W, Cin, Cout);      // Winograd plans: V + M planes
   return ssp_conv_ws_floats(B * H * W, Cin, Cout, R, plan);
+}
+int ssp_wino_filter_transform(const float* w9, float* U, int rows, int K, void* stream) {
+  return ssp_wino_filter_launch(w9, U, rows, K, (hipStream_t)stream);
 }
 
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,

@@ -20,6 +20,7 @@ import torch
 from . import _lib
 from .cfg import layer_shapes, resolve_layers
 
+WINO = 9000000       # plan codes WINO + tile_rows*100 + 10 + ring_slots: Winograd F(2x2, 3x3) evaluation (csrc/conv_wino.hip)
 BN_EPS = 1e-4        # darknet.py:157
 BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
 
@@ -295,6 +296,7 @@ class Plan(object):
         self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
         self.wversion = {}
+        self.wino_version = {}
         self.bnversion = {}
         self.generation = 0
         # flat gradient buffer layout, in backward (reverse layer) order so that all-reduce buckets close early:
@@ -345,6 +347,18 @@ class Plan(object):
         if getattr(cs, 'wbuf', None) is None:
             cs.wbuf = torch.empty(cs.cout * cs.k * cs.k * cs.cinp, dtype=torch.float32, device=self.device)
         return cs.wbuf
+
+    def _wino_u(self, cs):
+        """Winograd-transformed forward filters [16][Cout][Cin] of a layer whose forward plan is a Winograd code."""
+        if getattr(cs, 'wino_u', None) is None:
+            cs.wino_u = torch.empty(16 * cs.cout * cs.cinp, dtype=torch.float32, device=self.device)
+        return cs.wino_u
+
+    def _wino_ud(self, cs):
+        """... and of the data-gradient operand [16][Cin][Cout] (from the flipped / transposed [Cin][tap][Cout] layout)."""
+        if getattr(cs, 'wino_ud', None) is None:
+            cs.wino_ud = torch.empty(16 * cs.cin * cs.coutp, dtype=torch.float32, device=self.device)
+        return cs.wino_ud
 
     def _gbuf(self, cs):
         if getattr(cs, 'gbuf', None) is None:
@@ -426,6 +440,9 @@ class Plan(object):
                 src.record_stream(stream)
         _lib.call('ssp_repack_dgrad_packed' if cs.packed else 'ssp_repack_dgrad', src.data_ptr(),
                   _ptr(self._dpack, cs.doff), cs.cout, cs.cin, cs.coutp, cs.k, stream.cuda_stream)
+        if cs.plan_dgrad >= WINO:      # Winograd data-gradient plan: its filter operand is the transform of that layout
+            _lib.call('ssp_wino_filter_transform', _ptr(self._dpack, cs.doff), self._wino_ud(cs).data_ptr(), cs.cin,
+                      cs.coutp, stream.cuda_stream)
 
     # ------------------------------------------------------------------ per-shape tile / split selection
     def _autotune(self, which):
@@ -456,9 +473,27 @@ class Plan(object):
         elig = [cs for cs in self.convs.values() if cs.cinp % 16 == 0]
         if not elig:
             return
+        # Winograd F(2x2, 3x3) candidates (csrc/conv_wino.hip): 16/36 of the multiplies at the price of two HBM-bound
+        # transform passes - timed against the direct plans on the 3x3 layers with >= 256 channels on both sides (the
+        # transforms cost more than the GEMM saves on the wide maps with few channels).  SSP_WINOGRAD=0 turns them off.
+        wino_cands = (WINO + 6413, WINO + 6414, WINO + 12813, WINO + 12814)
+        wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
+
+        def wino_ok(cs, which):
+            return (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= 256)
         def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x4 mid, none big)
             mc = cs.M * max(cs.coutp, cs.cinp)
-            return 9 * mc if mc <= (1 << 21) else (4 * mc if mc <= (1 << 25) else 1)
+            need = 9 * mc if mc <= (1 << 21) else (4 * mc if mc <= (1 << 25) else 1)
+            # ... and what the library's own heuristic (plan 0: the reference launch of verify-after-tune) asks for: it may
+            # split K on a shape the candidate list does not (batch 64 at 832 x 832: the 26 x 26 layers, x3)
+            need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, 0))
+            if not cs.first:
+                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, 0))
+            if wino_ok(cs, which):
+                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, wino_cands[0]))
+                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, wino_cands[0]))
+            return need
         max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
         stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32) if which == 'fwd' else None
@@ -467,7 +502,7 @@ class Plan(object):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(1234)
 
-        def best_of(launch, mn, key):
+        def best_of(launch, mn, key, extra=()):
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
                 return _TUNE_CACHE[key]
             best, best_t = 0, None
@@ -475,8 +510,8 @@ class Plan(object):
             # deep K splits put every CU on the weight stream
             deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4, 8)) \
                 if mn <= (1 << 21) else ()
-            for code in cands + (lat if mn <= (1 << 23) else ()) + deep:
-                if ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
+            for code in cands + (lat if mn <= (1 << 23) else ()) + deep + tuple(extra):
+                if code < WINO and ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
                 try:
                     launch(code)
@@ -496,8 +531,9 @@ class Plan(object):
             _TUNE_CACHE[key] = best
             return best
 
-        def admitted(code, key, launch, out_of, operands, bn_of=None):
-            """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands."""
+        def admitted(code, key, launch, out_of, operands, bn_of=None, prep=None):
+            """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands.  A Winograd
+            plan is another ALGORITHM, not another summation order: its bar is 3e-5 of the output's range (measured ~1e-6)."""
             if code == 0 or not verify or key in _TUNE_VERIFIED:
                 return code
             # Operands are the plan's own buffers (they hold no data yet: tuning runs before the first forward, and
@@ -505,6 +541,9 @@ class Plan(object):
             # a torch.zeros-allocated activation must stay zero for its consumers.
             for t in operands:
                 (t[0].view(-1, t[1])[:, t[2]:t[2] + t[3]] if isinstance(t, tuple) else t).uniform_(-1.0, 1.0, generator=gen)
+            if prep is not None:
+                prep()                # operands changed: derived operands (Winograd-transformed filters) follow
+            bar = 3e-5 if code >= WINO else 1e-5
             res = []
             for c in (0, code):
                 launch(c)
@@ -516,7 +555,7 @@ class Plan(object):
             for a, b in zip(res[0], res[1]):
                 den = float(a.abs().max())
                 err = float((a - b).abs().max())
-                if not (err <= 1e-5 * max(den, 1e-30)):      # also false for NaN
+                if not (err <= bar * max(den, 1e-30)):      # also false for NaN
                     ok = False
             if ok:
                 _TUNE_VERIFIED.add(key)
@@ -534,8 +573,14 @@ class Plan(object):
                 wop = cs.conv.weight if cs.cinp == cs.cin else self._wbuf(cs)
                 key = ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn))
 
+                wino = wino_ok(cs, which)
+
+                def prep_f(cs=cs, wop=wop):
+                    call('ssp_wino_filter_transform', wop.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp, st)
+
                 def launch(code, cs=cs, wop=wop):
-                    call('ssp_conv_fwd', cs.inp.ptr, wop.data_ptr(), cs.raw.data_ptr(), None,
+                    wt = self._wino_u(cs) if code >= WINO else wop
+                    call('ssp_conv_fwd', cs.inp.ptr, wt.data_ptr(), cs.raw.data_ptr(), None,
                          stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
                          cs.k, 0, code, ws.data_ptr(), max_ws, st)
 
@@ -550,21 +595,37 @@ class Plan(object):
                          BN_EPS, tmp[4].data_ptr(), tmp[5].data_ptr(), tmp[6].data_ptr(), tmp[7].data_ptr(), st)
                     return [tmp[4, :cs.cout].clone(), tmp[5, :cs.cout].clone()]
 
-                code = best_of(launch, cs.M * cs.coutp, key)
+                if wino and key not in _TUNE_CACHE:
+                    prep_f()
+                code = best_of(launch, cs.M * cs.coutp, key, wino_cands if wino else ())
                 a = cs.inp
                 cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [(a.t, a.ld, a.off % a.ld, cs.cinp)] +
-                                       ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None)
+                                       ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None,
+                                       prep_f if code >= WINO else None)
+                if cs.plan_fwd < WINO:
+                    cs.wino_u = None          # not chosen: the transformed-filter buffer goes back to the allocator
             if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
                 key = self._dgrad_key(cs)
                 wslice = self._dpack[cs.doff:cs.doff + cs.cinp * cs.k * cs.k * cs.coutp]
 
+                wino = wino_ok(cs, which)
+
+                def prep_d(cs=cs):
+                    call('ssp_wino_filter_transform', _ptr(self._dpack, cs.doff), self._wino_ud(cs).data_ptr(), cs.cin,
+                         cs.coutp, st)
+
                 def launch(code, cs=cs):
-                    call('ssp_conv_dgrad', cs.raw.data_ptr(), _ptr(self._dpack, cs.doff), gscratch.data_ptr(), B, cs.H,
+                    wt = self._wino_ud(cs).data_ptr() if code >= WINO else _ptr(self._dpack, cs.doff)
+                    call('ssp_conv_dgrad', cs.raw.data_ptr(), wt, gscratch.data_ptr(), B, cs.H,
                          cs.W, cs.coutp, cs.cin, cs.ldraw, cs.inp.ld, cs.k, 0, code, ws.data_ptr(), max_ws, st)
 
-                code = best_of(launch, cs.M * cs.cinp, key)
+                if wino and key not in _TUNE_CACHE:
+                    prep_d()
+                code = best_of(launch, cs.M * cs.cinp, key, wino_cands if wino else ())
                 cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld],
-                                         [(cs.raw, cs.ldraw, 0, cs.cout), wslice])
+                                         [(cs.raw, cs.ldraw, 0, cs.cout), wslice], None, prep_d if code >= WINO else None)
+                if cs.plan_dgrad < WINO:
+                    cs.wino_ud = None
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
@@ -604,8 +665,23 @@ class Plan(object):
                     stale.append((cs, key))
         if need_grad:
             self._prepare_backward()
+        # Winograd-plan layers read TRANSFORMED filters: re-derived when the weights may have changed (every training
+        # step; in eval when a parameter version / the weights epoch moved), on the side stream like the repacks
+        wino = []
+        for cs in self.convs.values():
+            if cs.plan_fwd >= WINO:
+                wt = cs.conv.weight
+                wkey = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
+                if inline_repack or training or self.wino_version.get(cs.ind) != wkey:
+                    wino.append((cs, wkey))
         wait_for = {}
-        if stale or need_grad:
+        if inline_repack:
+            for cs, _ in wino:       # graph capture: part of the captured chain
+                src = cs.conv.weight if cs.packed else self._wbuf(cs)
+                call('ssp_wino_filter_transform', src.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp, st)
+                self.wino_version.pop(cs.ind, None)
+            wino = []
+        if stale or need_grad or wino:
             if self.side_stream is None:
                 self.side_stream = torch.cuda.Stream(device=self.device)
             side = self.side_stream
@@ -622,6 +698,15 @@ class Plan(object):
                     ev = side.record_event()
                     for cs, _ in group:
                         wait_for[cs.ind] = ev
+            if wino:
+                for cs, wkey in wino:
+                    src = cs.conv.weight if cs.packed else self._wbuf(cs)
+                    call('ssp_wino_filter_transform', src.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp,
+                         side.cuda_stream)
+                    self.wino_version[cs.ind] = wkey
+                ev = side.record_event()
+                for cs, _ in wino:
+                    wait_for[cs.ind] = ev
         if need_grad:
             for ind in sorted(self.convs.keys(), reverse=True):
                 cs = self.convs[ind]
@@ -659,6 +744,8 @@ class Plan(object):
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
                         self.bnversion[cs.ind] = None if inline_repack else bkey
                 wptr = cs.conv.weight.data_ptr() if cs.packed else self._wbuf(cs).data_ptr()
+                if cs.plan_fwd >= WINO:
+                    wptr = self._wino_u(cs).data_ptr()
                 cs.first_live = False
                 if cs.first_fused and not cs.packed and (training or not need_grad):
                     # training: statistics pass + apply pass; inference: the apply pass alone with the running-statistics
@@ -917,15 +1004,16 @@ class Plan(object):
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
                     scs = getattr(cs, 'bn_fuse_src', None)
+                    dwt = self._wino_ud(cs).data_ptr() if cs.plan_dgrad >= WINO else _ptr(self._dpack, cs.doff)
                     if scs is not None and src not in written:
                         sv = scs.vec
-                        call('ssp_conv_dgrad_bnbwd', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W,
+                        call('ssp_conv_dgrad_bnbwd', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W,
                              cs.coutp, cs.cin, dy_ld, gin.ld, cs.k, cs.plan_dgrad, self.ws.data_ptr(), self.ws_floats,
                              scs.raw.data_ptr(), scs.ldraw, sv[2].data_ptr(), sv[3].data_ptr(), sv[0].data_ptr(),
                              sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), scs.bnp[1], st)
                         fused_stats.add(src)
                     else:
-                        call('ssp_conv_dgrad', dy_ptr, _ptr(self._dpack, cs.doff), gin.ptr, B, cs.H, cs.W, cs.coutp,
+                        call('ssp_conv_dgrad', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W, cs.coutp,
                              cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
                              self.ws_floats, st)
                     written.add(src)

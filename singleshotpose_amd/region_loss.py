@@ -92,6 +92,10 @@ class _RegionLossBase(nn.Module):
         self.seen = 0
         self.pretrain_num_epochs = pretrain_num_epochs
         self.verbose = True      # print the reference's status line (one 32-byte device read per call)
+        # host labels reach the kernel through a pinned ring: 'copy' = asynchronous copy into a device twin, 'mapped' = the
+        # kernel reads the pinned buffer in place (zero copy)
+        import os
+        self.label_upload = os.environ.get('SSP_LABEL_UPLOAD', 'copy')
         self._last_stats = None
 
     def _upload(self, host_tensor, device):
@@ -119,15 +123,24 @@ class _RegionLossBase(nn.Module):
             # the copy that last read this pinned buffer (and the kernel that last read its device twin) were queued 4
             # calls ago: normally long finished, so this returns at once; a caller hopping streams is ordered by the wait
             slot['events'][i].synchronize()
+        t1 = time.perf_counter()
         slot['pin'][i].copy_(host_tensor)
-        slot['dev'][i].copy_(slot['pin'][i], non_blocking=True)
+        t2 = time.perf_counter()
+        if self.label_upload == 'mapped':
+            # pinned host memory is mapped into the GPU's address space: the kernel reads the labels (<= 269 KB, one pass)
+            # straight over PCIe - no copy engine, no asynchronous memcpy call on the host
+            out = slot['pin'][i]
+        else:
+            slot['dev'][i].copy_(slot['pin'][i], non_blocking=True)
+            out = slot['dev'][i]
         slot['used'][i] = True
         slot['release'] = (slot['events'][i], stream)      # recorded by forward() after the kernel that reads the labels
+        t3 = time.perf_counter()
         hist = self.__dict__.setdefault('upload_host_us', [])
-        hist.append((time.perf_counter() - t0) * 1e6)
+        hist.append(((t3 - t0) * 1e6, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6))   # total, ring wait, host copy, H2D issue
         if len(hist) > 4096:
             del hist[:2048]
-        return slot['dev'][i]
+        return out
 
     def last_stats(self):
         """Device tensor [loss_x, loss_y, loss_conf, loss_cls, total, nGT, nCorrect, nProposals] of the last call."""

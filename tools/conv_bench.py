@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--opt', default='', help='name=value,... passed to ssp_set_option')
     ap.add_argument('--wvariants', default='', help='comma list of wgrad_variant values to loop over')
     ap.add_argument('--variants', default='', help='comma list: run every case once per igemm_variant value')
+    ap.add_argument('--plans', default='0', help='comma list of explicit plan codes for fwd / dgrad (0 = heuristic; 9006413 etc. = '
+                                                 'Winograd: filters are transformed first, outside the timed launches)')
     ap.add_argument('--sweep', default='', help='option sets "name=value,...;name=value,..." (- = defaults): every case once per set, '
                                                 'in one process (options of the previous set are reset to 0)')
     args = ap.parse_args()
@@ -80,35 +82,46 @@ def run_cases(args, dev, st, B):
         dw = torch.zeros(Cout * R * R * Cin, device=dev)
         stats = torch.empty(((M + 63) // 64) * Cout * 2, device=dev)  # sized for the smallest M tile any variant uses
         flop = 2.0 * M * Cout * R * R * Cin
-        wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, 0), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, 0))
-        ws = torch.empty(wsn, device=dev)
-        fns = {
-            'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), w.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
-                                     B, H, W, Cin, Cout, Cin, coutp, R, 0, 0, ws.data_ptr(), wsn, st),
-            'dgrad': lambda: _lib.call('ssp_conv_dgrad', dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin,
-                                       coutp, Cin, R, 0, 0, ws.data_ptr(), wsn, st),
-            'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
-                                       coutp, Cin, R, st),
-        }
-        line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d |' % (name, H, Cin, Cout, R)
-        for op in args.ops.split(','):
-            if op == 'dgrad' and name == 'l0':
+        for plan in [int(v) for v in args.plans.split(',')]:
+            wino = plan >= 9000000
+            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout <= 64 or Cin <= 64):
                 continue
-            fn = fns[op]
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(args.iters):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn()
-                e1.record()
-                e1.synchronize()
-                ts.append(e0.elapsed_time(e1))
-            med = float(np.median(ts))
-            line += ' %s %7.1f us %6.1f TF |' % (op, med * 1e3, flop / (med * 1e-3) / 1e12)
-        print(line, flush=True)
+            wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, plan), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, plan))
+            ws = torch.empty(wsn, device=dev)
+            wf, wdd = w, wd
+            if wino:
+                wf = torch.empty(16 * Cout * Cin, device=dev)
+                wdd = torch.empty(16 * Cin * coutp, device=dev)
+                _lib.call('ssp_wino_filter_transform', w.data_ptr(), wf.data_ptr(), Cout, Cin, st)
+                _lib.call('ssp_wino_filter_transform', wd.data_ptr(), wdd.data_ptr(), Cin, coutp, st)
+            fns = {
+                'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), wf.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
+                                         B, H, W, Cin, Cout, Cin, coutp, R, 0, plan, ws.data_ptr(), wsn, st),
+                'dgrad': lambda: _lib.call('ssp_conv_dgrad', dy.data_ptr(), wdd.data_ptr(), dx.data_ptr(), B, H, W, coutp, Cin,
+                                           coutp, Cin, R, 0, plan, ws.data_ptr(), wsn, st),
+                'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
+                                           coutp, Cin, R, st),
+                'wfilt': lambda: _lib.call('ssp_wino_filter_transform', w.data_ptr(), wf.data_ptr(), Cout, Cin, st),
+            }
+            line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d plan %7d |' % (name, H, Cin, Cout, R, plan)
+            for op in args.ops.split(','):
+                if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])):
+                    continue
+                fn = fns[op]
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(args.iters):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                med = float(np.median(ts))
+                line += ' %s %7.1f us %6.1f TF |' % (op, med * 1e3, flop / (med * 1e-3) / 1e12)
+            print(line, flush=True)
 
 
 if __name__ == '__main__':

@@ -21,12 +21,15 @@ sys.path.insert(0, ROOT)
 def main():
     from singleshotpose_amd.region_loss import RegionLoss, RegionLossMulti
     dev = torch.device('cuda', 0)
-    rounds, calls = 10, 500
+    rounds, calls = 4, 500
     out = {}
-    for name, crit, ch, nlab in (('single', RegionLoss(), 20, 1),
-                                 ('multi', RegionLossMulti(anchors=[1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018,
-                                                                    3.9910, 3.4879, 5.8851]), 160, 8)):
+    anchors = [1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018, 3.9910, 3.4879, 5.8851]
+    for name, crit, ch, nlab, mode in (('single_copy', RegionLoss(), 20, 1, 'copy'), ('single_mapped', RegionLoss(), 20, 1, 'mapped'),
+                                       ('single_device_labels', RegionLoss(), 20, 1, 'device'),
+                                       ('single_copy_sync_every_32', RegionLoss(), 20, 1, 'copy32'),
+                                       ('multi_copy', RegionLossMulti(anchors=anchors), 160, 8, 'copy')):
         crit.verbose = False
+        crit.label_upload = 'mapped' if mode == 'mapped' else 'copy'
         head = torch.randn(64, ch, 13, 13, device=dev, requires_grad=True)
         g = torch.Generator().manual_seed(0)
         t = torch.zeros(64, 50, 21, dtype=torch.float64)
@@ -35,6 +38,8 @@ def main():
             t[:, k, 1:19] = torch.rand(64, 18, generator=g, dtype=torch.float64) * 0.5 + 0.25
             t[:, k, 19:21] = 0.2
         tgt = t.view(64, -1)
+        if mode == 'device':
+            tgt = tgt.to(dev)
         rec = []
         for r in range(rounds):
             torch.cuda.synchronize()
@@ -42,14 +47,20 @@ def main():
             ts = np.empty(calls)
             for i in range(calls):
                 t0 = time.perf_counter()
-                crit(head, tgt.clone() if i % 7 == 0 else tgt, 20)      # a fresh label tensor now and then, as a DataLoader yields
+                crit(head, tgt.clone() if (i % 7 == 0 and mode != 'device') else tgt, 20)      # a fresh label tensor now and then, as a DataLoader yields
                 ts[i] = (time.perf_counter() - t0) * 1e6
+                if mode == 'copy32' and i % 32 == 31:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
-            up = np.asarray(crit.upload_host_us[-calls:])
+            det = np.asarray(crit.upload_host_us[-calls:]) if mode != 'device' else np.zeros((calls, 4))
+            up = det[:, 0]
+            worst = int(np.argmax(ts))
             rec.append(dict(call_us=dict(median=round(float(np.median(ts)), 1), p99=round(float(np.percentile(ts, 99)), 1),
                                          max=round(float(ts.max()), 1)),
                             upload_us=dict(median=round(float(np.median(up)), 1), p99=round(float(np.percentile(up, 99)), 1),
                                            max=round(float(up.max()), 1)),
+                            worst_call=dict(index=worst, call_us=round(float(ts[worst]), 1), ring_wait_us=round(float(det[worst, 1]), 1),
+                                            host_copy_us=round(float(det[worst, 2]), 1), h2d_issue_us=round(float(det[worst, 3]), 1)),
                             slow_calls=[(int(i), round(float(ts[i]), 1)) for i in np.nonzero(ts > 500.0)[0][:8]]))
         out[name] = rec
     print(json.dumps(out))
