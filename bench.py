@@ -478,12 +478,39 @@ def main():
         traffic, traffic_src = forward_traffic_per_launch()
         images_per_s = global_batch * args.steps / dt
 
-        def family(kernel, ms_, flop_, n_, note):
+        # `achieved` counts ALGORITHMIC FLOPs (direct convolution, 2*M*Cout*9*Cin): layers the autotuner runs in the Winograd
+        # F(2x2,3x3) domain (plan codes >= 9000000, csrc/conv_wino.hip) execute 16/36 of those multiplies (x tile padding), so
+        # their fraction of the MFMA peak can exceed 1.  `executed` is the same time against the FLOPs the matrix pipe really
+        # issued - the utilisation figure.
+        plan0 = next(iter(model._plans.values()))
+        alg = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+        exe = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+        wino_layers = {'fwd': [], 'dgrad': [], 'wgrad': []}
+        for ind, cs in sorted(plan0.convs.items()):
+            if cs.first:
+                continue
+            direct = 2.0 * cs.M * cs.cout * cs.k * cs.k * cs.cin
+            tiles = B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2)
+            wino = 2.0 * 16 * tiles * cs.cin * cs.cout
+            for fam, on in (('fwd', cs.plan_fwd >= 9000000), ('dgrad', cs.plan_dgrad >= 9000000),
+                            ('wgrad', bool(getattr(cs, 'wgrad_wino', False)))):
+                alg[fam] += direct
+                exe[fam] += wino if on else direct
+                if on:
+                    wino_layers[fam].append(ind)
+
+        def executed(fam, ms_):
+            tf = exe[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            return {"achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "flop_per_step": exe[fam],
+                    "winograd_layers": wino_layers[fam],
+                    "note": "FLOPs the MFMA pipe issued (Winograd layers: 16 GEMMs of tiles x Cin x Cout) / the same time"}
+
+        def family(fam, kernel, ms_, flop_, n_, note):
             tf = flop_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
             return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(ms_ / max(n_, 1), 4), "launches_per_step": n_,
-                    "ms_per_step": round(ms_, 3), "flop_per_step": flop_, "note": note}
+                    "ms_per_step": round(ms_, 3), "flop_per_step": flop_, "executed": executed(fam, ms_), "note": note}
         res = {
             "metric": "images/sec (fwd+bwd) yolo-pose 416x416 bs=64/GPU",
             "value": round(images_per_s, 2),
@@ -505,7 +532,8 @@ def main():
             "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma",
                          "kernel": "conv_igemm_dma_kernel<BM, BN, 0, NSLOT, WM, WN>(ConvArgs): the forward launches of "
-                                   "layers 2-30 (the first block's two passes are first_block_kernel<0|1>, reported under "
+                                   "layers 2-30 (Winograd-plan layers: + wino_input_kernel, reduce_kernel<true>; the first "
+                                   "block's two passes are first_block_kernel<0|1>, reported under "
                                    "kernel_ms_per_step.first_block_fwd, not here)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -513,12 +541,15 @@ def main():
                          "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
                          "launches_per_step": ig_n / ig_steps,
                          "flop_per_launch_avg": ig_flop / max(ig_n, 1),
-                         "note": "HIP events around exactly these launches inside the timed region (they run alone on the GPU)"},
-            "roofline_dgrad": family("conv_igemm_dma_kernel<BM, BN, 1, NSLOT, WM, WN>(ConvArgs) (+ conv_igemm_kernel<64, 128, "
+                         "executed": executed('fwd', ig_ms / max(ig_steps, 1)),
+                         "note": "HIP events around exactly these launches inside the timed region (they run alone on the GPU); "
+                                 "a Winograd-plan layer's three launches (input transform, batched GEMM, finishing pass) are "
+                                 "one timed unit; achieved = algorithmic FLOPs / time (see `executed` for pipe utilisation)"},
+            "roofline_dgrad": family("dgrad", "conv_igemm_dma_kernel<BM, BN, 1, NSLOT, WM, WN>(ConvArgs) (+ conv_igemm_kernel<64, 128, "
                                      "2, 2, 4, 0, 1> for the 20-channel head)", ex[1][0], ex[1][1], ex[1][2],
                                      "kernel-exclusive: untimed pass with the filter gradients on the same stream "
                                      "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues"),
-            "roofline_wgrad": family("conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs)", ex[2][0], ex[2][1],
+            "roofline_wgrad": family("wgrad", "conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs)", ex[2][0], ex[2][1],
                                      ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same stream "
                                      "(Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
                                      "(kernel_ms_per_step.first_block_bwd)"),

@@ -89,6 +89,13 @@ int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int
  * zeroed by the caller (split reduction uses fp32 atomics). */
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                    int ldx, int R, void* stream);
+/* The same filter gradient of a 3x3 layer (Cin, Cout >= 64 and % 16 == 0) evaluated in the Winograd F(2x2, 3x3) domain
+ * (csrc/conv_wino.hip): dw += the direct result to ~1e-6 of its range with 16/36 of the multiplies.  dw must be 16-byte
+ * aligned, [Cout][3][3][Cin] floats (the ssp_repack_fwd layout), written by this launch alone while it runs;
+ * workspace: ssp_conv_wgrad_wino_workspace_floats(...) floats. */
+int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int ssp_conv_wgrad_wino(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                        int ldx, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- BatchNorm2d(eps) + LeakyReLU(slope) (+ 2x2/2 max-pool): darknet.py:157,162,172 ------------------------- */
 int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,

@@ -35,6 +35,8 @@ _SIGS = {
     "ssp_conv_dgrad_bnbwd": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, I, P, P, P, P, F, P, I, P],
     "ssp_bn_act_bwd_partials": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, I, P, I, I, P, P, P, P, P],
     "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
+    "ssp_conv_wgrad_wino": [P, P, P, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_wgrad_wino_workspace_floats": [I, I, I, I, I],
     "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],
     "ssp_bn_eval_prepare": [I, P, P, P, P, F, P, P, P, P, P],
     "ssp_bn_act_fwd": [P, I, P, I, P, P, I, I, I, I, I, F, P],
@@ -74,7 +76,7 @@ _SIGS = {
     "ssp_prof_collect": [P, P, P],
 }
 
-_RET64 = ('ssp_conv_workspace_floats',)
+_RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats')
 
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
               "first_block_bwd")

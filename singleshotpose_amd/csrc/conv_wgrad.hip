@@ -351,7 +351,11 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
 }
 
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
-                           int ldx, int R, hipStream_t stream);   // conv_wgrad_dma.hip
+                           int ldx, int R, hipStream_t stream, int batch = 0, int64_t batch_dy = 0, int64_t batch_x = 0,
+                           int64_t batch_dw = 0);   // conv_wgrad_dma.hip
+int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int W, int C, hipStream_t stream);      // conv_wino.hip
+int ssp_wino_outgrad_launch(const float* dy, int lddy, float* dM, int B, int H, int W, int C, hipStream_t stream);
+int ssp_wino_wgrad_finish_launch(const float* dU, float* dw, int rows, int K, hipStream_t stream);
 
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout,
                           int lddy, int ldx, int R, hipStream_t stream) {
@@ -390,4 +394,40 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
   if (bo == 32 && bi == 128) return launch_wgrad<32, 128, 1, 4, 1>(a, stream);
   if (bo == 32 && bi == 64) return launch_wgrad<32, 64, 1, 2, 2>(a, stream);
   return launch_wgrad<32, 32, 1, 1, 4>(a, stream);
+}
+
+
+// Filter gradient of a 3x3 layer in the Winograd domain (conv_wino.hip): transform the input (B^T d B) and the output
+// gradient (A dY A^T) into 16 planes each, contract the planes pairwise over the tiles in ONE batched launch of the
+// LDS-direct filter-gradient kernel, map the 16 results back onto the 9 taps (G^T . G) and add them to dw.
+// workspace: V [16][T][Cin] | dM [16][T][Cout] | dU [16][Cout][Cin] (ssp_conv_wgrad_wino_ws_floats).
+int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout) {
+  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return 16 * (T * ((int64_t)Cin + Cout) + (int64_t)Cin * Cout);
+}
+int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                               int ldx, float* ws, int64_t ws_floats, hipStream_t stream) {
+  SSP_CHECK_ARG(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 64 && Cout >= 64, "wgrad (Winograd): needs Cin, Cout >= 64 and %% 16 == 0");
+  SSP_CHECK_ARG(ldx % 4 == 0 && ldx >= Cin && lddy % 4 == 0 && lddy >= Cout, "wgrad (Winograd): bad leading dimensions");
+  SSP_CHECK_ARG((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)ws)) % 16 == 0, "wgrad (Winograd): operands must be 16-byte aligned");
+  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  SSP_CHECK_ARG(T >= 128 && T < (1ll << 31), "wgrad (Winograd): tile count out of range");
+  SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout),
+                "wgrad (Winograd): needs a workspace of %lld floats (ssp_conv_wgrad_wino_workspace_floats)",
+                (long long)ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout));
+  SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)B * H * W * Cout * 9.0 * Cin);      // algorithmic (direct) FLOPs
+  float* V = ws;
+  float* dM = V + 16 * T * Cin;
+  float* dU = dM + 16 * T * Cout;
+  if (int rc = ssp_wino_input_launch(x, ldx, V, B, H, W, Cin, stream)) return rc;
+  if (int rc = ssp_wino_outgrad_launch(dy, lddy, dM, B, H, W, Cout, stream)) return rc;
+  if (hipMemsetAsync(dU, 0, (size_t)16 * Cin * Cout * 4, stream) != hipSuccess) {
+    ssp_set_error("wgrad (Winograd): hipMemsetAsync failed");
+    return SSP_ERR_HIP;
+  }
+  const int r = ssp_conv_wgrad_dma_try(dM, V, dU, 1, 1, (int)T, Cin, Cout, Cout, Cin, 1, stream, 16, T * Cout, T * Cin,
+                                       (int64_t)Cout * Cin);
+  if (r < 0) return r;
+  SSP_CHECK_ARG(r == 1, "wgrad (Winograd): shape declined by the LDS-direct filter-gradient kernel");
+  return ssp_wino_wgrad_finish_launch(dU, dw, Cout, Cin, stream);
 }

@@ -24,6 +24,10 @@ struct WgradArgs {
   int xcd_order;  // XCD-aware workgroup order (see the kernel): 1 = all tiles of a pixel range on one XCD, 2 = per (range, cout tile)
   int no_store;   // 2: generic epilogue (A/B switch, same results); 1: SSP_PROBES builds only - skip the atomic epilogue
   int fold;   // filter taps per cin tile: 1, or BNI / Cin when Cin < BNI (thin layers: two taps of 32 cins share a tile)
+  // batched launch (the 16 transform positions of a Winograd filter gradient, conv_wino.hip): gridDim.y problems of one
+  // shape; problem b reads dy + b * batch_dy, x + b * batch_x and accumulates into dw + b * batch_dw.  0 / 1: one problem.
+  int batch;
+  int64_t batch_dy, batch_x, batch_dw;
 };
 
 #define SSP_OOB 0x80000000u
@@ -115,6 +119,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the scalar pixel walker depends on it
   const int wm = wid / WN, wn = wid % WN;
   const int li = lane & 31, lh = lane >> 5;
+  const int64_t bz = (p.batch > 1) ? (int64_t)blockIdx.y : 0;   // batched launch: problem index (scalar)
+  const float* const dy_b = p.dy + bz * p.batch_dy;
+  const float* const x_b = p.x + bz * p.batch_x;
+  float* const dw_b = p.dw + bz * p.batch_dw;
 
   // ---- loader lanes: piece g (1 KiB) of a tile = bytes [g*1024, g*1024+1024) of the row-major [16][C] image ----
   // A 1-KiB piece of the X tile covers RP consecutive pixel rows (BNI = 128: 2 rows of 512 B, BNI = 64: 4 rows of
@@ -168,9 +176,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
     const int left = m_end - ld_m;                       // pixel rows still inside this workgroup's range
     const int64_t abase = (int64_t)ld_m * p.lddy;
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.dy + abase), 0, left > 0 ? (int)min((int64_t)left * p.lddy * 4, (int64_t)0x7fffffff) : 0, 0x00020000);
+        (void*)(dy_b + abase), 0, left > 0 ? (int)min((int64_t)left * p.lddy * 4, (int64_t)0x7fffffff) : 0, 0x00020000);
     rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + ((int64_t)ld_m - p.W - 1) * p.ldx), 0, (int)SSP_OOB, 0x00020000);   // base = pixel (y-1, x-1)
+        (void*)(x_b + ((int64_t)ld_m - p.W - 1) * p.ldx), 0, (int)SSP_OOB, 0x00020000);   // base = pixel (y-1, x-1)
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
       if constexpr (FOLD) {
@@ -327,7 +335,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
   const int64_t row_floats = (int64_t)taps * p.Cin;                       // floats between consecutive filters of dw
   if (!FOLD && co0 + BMO <= p.Cout && (int64_t)BMO * row_floats * 4 < (1ll << 31) && p.no_store != 2) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.dw + ((int64_t)co0 * taps + tap) * p.Cin), 0, (int)(BMO * row_floats * 4), 0x00020000);
+        (void*)(dw_b + ((int64_t)co0 * taps + tap) * p.Cin), 0, (int)(BMO * row_floats * 4), 0x00020000);
     const int row4 = (int)row_floats * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -357,7 +365,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * WTM + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
-        if (co < p.Cout && ci < p.Cin && tl < taps) atomicAdd(p.dw + ((int64_t)co * taps + tl) * p.Cin + ci, acc[i][j][r]);
+        if (co < p.Cout && ci < p.Cin && tl < taps) atomicAdd(dw_b + ((int64_t)co * taps + tl) * p.Cin + ci, acc[i][j][r]);
       }
     }
 #endif
@@ -373,7 +381,8 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
 #ifdef SSP_PROBES
   if (ssp_option(SSP_OPT_WGRAD_VARIANT) == 9) a.no_store = 1;
 #endif
-  const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold);
+  const int nbatch = a.batch > 1 ? a.batch : 1;
+  const int64_t tiles = (int64_t)a.ntile_co * a.ntile_ci * ssp_cdiv(a.R * a.R, a.fold) * nbatch;   // all problems of the launch
   const int lds_bytes = NSLOT * RA * (BMO + BNI) * 4;
   auto kern = conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>;
   static SspKernelCache cache;   // per instantiation, per device
@@ -389,7 +398,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   // measured (profiles/r03_convbench_wgrad.txt): no gain over the plain order on layers 18 - 29 (117.6 / 124.3 / 131.3 TF against
   // 120.9 / 125.1 / 129.9): their operands (44 MB each) live in the 256 MB Infinity Cache and the kernel is not bound by
   // that traffic - kept as an experiment switch (wgrad_variant 20), off by default
-  const bool order2 = variant == 20 && !FOLD && tiles > 64 && max_split >= 16 && a.R * a.R * a.ntile_ci <= 128;
+  const bool order2 = variant == 20 && nbatch == 1 && !FOLD && tiles > 64 && max_split >= 16 && a.R * a.R * a.ntile_ci <= 128;
   int64_t lo = ((int64_t)slots + tiles - 1) / tiles, hi = ((order2 ? 8 : 5) * (int64_t)slots) / tiles;
   if (tiles >= (int64_t)(0.93 * slots)) lo = 1;        // the tiles alone (almost) fill a wave
   if (variant == 4) lo = (2 * (int64_t)slots + tiles - 1) / tiles;   // experiment: at least two waves (the old rule)
@@ -399,7 +408,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   if (hi > max_split) hi = max_split;
   // XCD-aware order (see the kernel) when the workgroups of one pixel range fit one XCD's resident set (64); the split
   // is then a multiple of 8 so that every XCD gets the same number of pixel ranges
-  a.xcd_order = (variant != 10 && tiles <= 64 && max_split >= 16) ? 1 : 0;
+  a.xcd_order = (variant != 10 && tiles <= 64 && max_split >= 16 && nbatch == 1) ? 1 : 0;
   // More tiles than that (the 13 x 13 layers): units of (pixel range, cout tile) dealt to the XCDs (order 2); the split is
   // chosen so that the units divide evenly over the 8 XCDs (or are many enough for the remainder not to matter)
   const int64_t step = a.xcd_order ? 8 : 1;
@@ -434,14 +443,15 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
     const int64_t units = nsplit * a.ntile_co, gu = (int64_t)ssp_cdiv(a.R * a.R, a.fold) * a.ntile_ci;
     nwg = 8 * gu * ((units + 7) / 8);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nwg / nbatch), nbatch), dim3(256), lds_bytes, stream, a);
   SSP_CHECK_LAUNCH("conv_wgrad_dma");
   return SSP_OK;
 }
 
 // returns 1 when the shape is handled here (launched), 0 when the caller should use conv_wgrad.hip, < 0 on error
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
-                           int ldx, int R, hipStream_t stream) {
+                           int ldx, int R, hipStream_t stream, int batch, int64_t batch_dy, int64_t batch_x,
+                           int64_t batch_dw) {
   if (Cout < 64 || (Cin < 64 && !(Cin == 32 && R == 3))) return 0;   // Cin 32: two taps fold into one 64-column tile
   if (W < 8) return 0;   // the per-lane pixel walker advances 16 pixels with at most two row wraps
   const int64_t M = (int64_t)B * H * W;
@@ -450,6 +460,7 @@ int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, in
   WgradArgs a;
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = (int)M;
+  a.batch = batch; a.batch_dy = batch_dy; a.batch_x = batch_x; a.batch_dw = batch_dw;
   int rc;
   const int wv = ssp_option(SSP_OPT_WGRAD_VARIANT);
   if (Cin == 32) rc = (Cout >= 128) ? launch_wgrad_dma<128, 64, 4, true>(a, stream) : launch_wgrad_dma<64, 64, 4, true>(a, stream);

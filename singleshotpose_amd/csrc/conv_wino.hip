@@ -109,6 +109,116 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
   }
 }
 
+// ---- filter gradient in the transform domain --------------------------------------------------------------------------
+// dL/dU_xi [Cout][Cin] = sum_t dM_xi[t][Cout] (x) V_xi[t][Cin]   with   dM = A dY A^T  (the adjoint of the inverse transform:
+// a 2x2 tile of the output gradient spread over the 4x4 domain, A = [1 0; 1 1; 1 -1; 0 -1]) and V the transformed input of
+// the forward pass; then dL/dg = G^T (dL/dU) G.  The 16 sums over the tiles are 16 pixel-contraction GEMMs - one batched
+// launch of the LDS-direct filter-gradient kernel (conv_wgrad_dma.hip, R = 1, gridDim.y = 16) - with 16/36 of the direct
+// kernel's multiplies.
+struct WinoOutGradArgs {
+  const float* dy;   // [B*H*W][lddy]
+  float* dM;         // [16][T][C]
+  int H, W, C, lddy, th, tw;
+  int64_t T;
+  SspFastDiv div_c4, div_tw, div_th;
+};
+
+__global__ void __launch_bounds__(256) wino_outgrad_kernel(WinoOutGradArgs p) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = p.C >> 2;
+  if (gid >= p.T * c4n) return;
+  const unsigned t = ssp_div((unsigned)gid, p.div_c4);
+  const int c = (int)((unsigned)gid - t * (unsigned)c4n) * 4;
+  const unsigned q = ssp_div(t, p.div_tw);
+  const int tx = (int)(t - q * (unsigned)p.tw);
+  const unsigned b = ssp_div(q, p.div_th);
+  const int ty = (int)(q - b * (unsigned)p.th);
+  const float* base = p.dy + ((int64_t)b * p.H * p.W) * p.lddy + c;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = 2 * ty + i, x = 2 * tx + j;
+      d[i][j] = (y < p.H && x < p.W) ? *reinterpret_cast<const f32x4*>(base + ((int64_t)y * p.W + x) * p.lddy) : z;
+    }
+  // A d: rows (d0, d0 + d1, d0 - d1, -d1); then the same over the columns
+  f32x4 r[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    r[0][j] = d[0][j];
+    r[1][j] = d[0][j] + d[1][j];
+    r[2][j] = d[0][j] - d[1][j];
+    r[3][j] = z - d[1][j];
+  }
+  float* dst = p.dM + (int64_t)t * p.C + c;
+  const int64_t plane = p.T * p.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(dst + (int64_t)(i * 4 + 0) * plane) = r[i][0];
+    *reinterpret_cast<f32x4*>(dst + (int64_t)(i * 4 + 1) * plane) = r[i][0] + r[i][1];
+    *reinterpret_cast<f32x4*>(dst + (int64_t)(i * 4 + 2) * plane) = r[i][0] - r[i][1];
+    *reinterpret_cast<f32x4*>(dst + (int64_t)(i * 4 + 3) * plane) = z - r[i][1];
+  }
+}
+
+// dw[row][tap][k] += (G^T dU G)[tap]; thread = (row, 4 k's); dw is this launch's own (no other writer): plain read-add-write
+__global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __restrict__ dU, float* dw, int rows, int K) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int k4n = K >> 2;
+  if (gid >= (int64_t)rows * k4n) return;
+  const int row = (int)(gid / k4n);
+  const int k = (int)(gid - (int64_t)row * k4n) * 4;
+  const float* src = dU + (int64_t)row * K + k;
+  const int64_t plane = (int64_t)rows * K;
+  f32x4 u[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[i][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)(i * 4 + j) * plane);
+  // G^T u: rows (u0 + (u1 + u2) / 2, (u1 - u2) / 2, (u1 + u2) / 2 + u3); then the same over the columns
+  f32x4 h[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[0][j] = u[0][j] + (u[1][j] + u[2][j]) * 0.5f;
+    h[1][j] = (u[1][j] - u[2][j]) * 0.5f;
+    h[2][j] = (u[1][j] + u[2][j]) * 0.5f + u[3][j];
+  }
+  float* dst = dw + ((int64_t)row * 9) * K + k;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f32x4* o0 = reinterpret_cast<f32x4*>(dst + (int64_t)(i * 3 + 0) * K);
+    f32x4* o1 = reinterpret_cast<f32x4*>(dst + (int64_t)(i * 3 + 1) * K);
+    f32x4* o2 = reinterpret_cast<f32x4*>(dst + (int64_t)(i * 3 + 2) * K);
+    *o0 = *o0 + (h[i][0] + (h[i][1] + h[i][2]) * 0.5f);
+    *o1 = *o1 + (h[i][1] - h[i][2]) * 0.5f;
+    *o2 = *o2 + ((h[i][1] + h[i][2]) * 0.5f + h[i][3]);
+  }
+}
+
+int ssp_wino_outgrad_launch(const float* dy, int lddy, float* dM, int B, int H, int W, int C, hipStream_t stream) {
+  WinoOutGradArgs a;
+  a.dy = dy; a.dM = dM; a.H = H; a.W = W; a.C = C; a.lddy = lddy;
+  a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
+  a.T = (int64_t)B * a.th * a.tw;
+  SSP_CHECK_ARG(C % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)dM) & 15) == 0,
+                "wino_outgrad: channels must be a multiple of 4 and the operands 16-byte aligned");
+  SSP_CHECK_ARG(a.T * (C / 4) < (1ll << 31), "wino_outgrad: too many (tile, channel) pairs");
+  a.div_c4 = ssp_fastdiv((unsigned)(C / 4)); a.div_tw = ssp_fastdiv((unsigned)a.tw); a.div_th = ssp_fastdiv((unsigned)a.th);
+  const int64_t n = a.T * (C / 4);
+  hipLaunchKernelGGL(wino_outgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  SSP_CHECK_LAUNCH("wino_outgrad");
+  return SSP_OK;
+}
+
+int ssp_wino_wgrad_finish_launch(const float* dU, float* dw, int rows, int K, hipStream_t stream) {
+  const int64_t n = (int64_t)rows * (K / 4);
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dU, dw, rows, K);
+  SSP_CHECK_LAUNCH("wino_wgrad_finish");
+  return SSP_OK;
+}
+
 int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int W, int C, hipStream_t stream) {
   WinoInArgs a;
   a.in = in; a.V = V; a.H = H; a.W = W; a.C = C; a.ldin = ldin;

@@ -18,6 +18,9 @@ int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout);
 int ssp_wino_filter_launch(const float* w, float* U, int rows, int K, hipStream_t stream);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
+int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout);
+int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                               int ldx, float* ws, int64_t ws_floats, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
                                const float* beta, float* rmean, float* rvar, float momentum, float eps, float* mean,
                                float* invstd, float* scale, float* shift, hipStream_t stream);
@@ -256,6 +259,14 @@ int ssp_first_bwd_wgrad(const float* x, const float* wt, const float* g, int ldg
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                    int ldx, int R, void* stream) {
   return ssp_conv_wgrad_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, R, (hipStream_t)stream);
+}
+
+int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout) {
+  return ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout);
+}
+int ssp_conv_wgrad_wino(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                        int ldx, float* workspace, int64_t workspace_floats, void* stream) {
+  return ssp_conv_wgrad_wino_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,

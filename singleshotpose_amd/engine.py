@@ -318,6 +318,7 @@ class Plan(object):
         self.grad_total = goff
         self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
         self.side_stream = None
+        self.ws_wgrad = None           # workspace of the Winograd-domain filter gradients (they run on the side stream)
         self.serial_backward = False   # measurement aid (bench.py): filter gradients on the MAIN stream, so that every
                                        # backward launch runs alone and its HIP-event duration is kernel-exclusive
         self.dgrad_ready = None
@@ -379,10 +380,12 @@ class Plan(object):
             self._dgrad_tuned = tune
             if self._tune and tune:
                 self._autotune('dgrad')
+                self._tune_wgrad()
             elif self._tune:
                 for cs in self.convs.values():
                     key = self._dgrad_key(cs)
                     cs.plan_dgrad = _TUNE_CACHE.get(key, 0) if key in _TUNE_VERIFIED else 0
+                    cs.wgrad_wino = False
             need = 1
             for cs in self.convs.values():
                 cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
@@ -394,6 +397,85 @@ class Plan(object):
                 self.ws_floats = need
                 self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
                 self._graph = None          # a captured inference chain holds the old workspace pointer
+
+    def _tune_wgrad(self):
+        """Filter gradients of the deep 3x3 layers: direct kernel or Winograd domain (ssp_conv_wgrad_wino), whichever is
+        faster on this shape; admitted only after its result on seeded operands agrees with the direct kernel's to 3e-5 of
+        the gradient's range.  Runs before the first forward of the plan (its operands are the plan's own, still empty,
+        buffers).  The choice is cached per launch shape like the igemm plans."""
+        call = _lib.call
+        st = torch.cuda.current_stream().cuda_stream
+        wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
+        verify = os.environ.get('SSP_TUNE_VERIFY', '1') != '0'
+        need = 1
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(4321)
+        n_known = len(_TUNE_CACHE)
+        for cs in self.convs.values():
+            cs.wgrad_wino = False
+            if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= 256 and
+                    self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 128):
+                continue
+            key = ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld)
+            wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout)
+            if key in _TUNE_CACHE and (key in _TUNE_VERIFIED or not verify or not _TUNE_CACHE[key]):
+                cs.wgrad_wino = bool(_TUNE_CACHE[key])
+            else:
+                ws = torch.empty(wsn, dtype=torch.float32, device=self.device)
+                dw = [torch.zeros(cs.cout * 9 * cs.cinp, dtype=torch.float32, device=self.device) for _ in range(2)]
+                a = cs.inp
+                a.t.view(-1, a.ld)[:, a.off % a.ld:a.off % a.ld + cs.cinp].uniform_(-1.0, 1.0, generator=gen)
+                cs.raw.view(-1, cs.ldraw)[:, :cs.cout].uniform_(-1.0, 1.0, generator=gen)
+
+                def direct(out, cs=cs):
+                    call('ssp_conv_wgrad', cs.raw.data_ptr(), cs.inp.ptr, out.data_ptr(), self.B, cs.H, cs.W, cs.cinp, cs.cout,
+                         cs.ldraw, cs.inp.ld, cs.k, st)
+
+                def wino(out, cs=cs, ws=ws, wsn=wsn):
+                    call('ssp_conv_wgrad_wino', cs.raw.data_ptr(), cs.inp.ptr, out.data_ptr(), self.B, cs.H, cs.W, cs.cinp,
+                         cs.cout, cs.ldraw, cs.inp.ld, ws.data_ptr(), wsn, st)
+
+                ts = []
+                try:
+                    for fn, out in ((direct, dw[0]), (wino, dw[1])):
+                        fn(out)                      # also the verification pair (first call into a zeroed buffer)
+                        best = None
+                        for _ in range(2):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            fn(torch.empty_like(out))
+                            e1.record()
+                            e1.synchronize()
+                            t = e0.elapsed_time(e1)
+                            best = t if best is None else min(best, t)
+                        ts.append(best)
+                    # verification pair: one accumulation each into zeroed buffers
+                    dw[0].zero_()
+                    dw[1].zero_()
+                    direct(dw[0])
+                    wino(dw[1])
+                    den = float(dw[0].abs().max())
+                    err = float((dw[0] - dw[1]).abs().max())
+                    ok = err <= 3e-5 * max(den, 1e-30)
+                except _lib.SspError:
+                    ts, ok = [0.0, 1.0], False
+                use = bool(ok and ts[1] < 0.985 * ts[0])
+                if not ok and ts[1] < ts[0]:
+                    TUNE_REJECTED.append((key, 'wgrad_wino'))
+                    import warnings
+                    warnings.warn("singleshotpose_amd: verify-after-tune refused the Winograd filter gradient for %s" % (key,))
+                _TUNE_CACHE[key] = 1 if use else 0
+                if ok:
+                    _TUNE_VERIFIED.add(key)
+                cs.wgrad_wino = use
+                del ws, dw
+            if cs.wgrad_wino:
+                need = max(need, wsn)
+        torch.cuda.synchronize()
+        self.ws_wgrad = torch.empty(need, dtype=torch.float32, device=self.device) if need > 1 else None
+        if len(_TUNE_CACHE) != n_known:
+            _tune_cache_save()
 
     def _dgrad_key(self, cs):
         return ('dgrad', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld)
@@ -503,8 +585,12 @@ class Plan(object):
         gen.manual_seed(1234)
 
         def best_of(launch, mn, key, extra=()):
+            keep = True
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
-                return _TUNE_CACHE[key]
+                if _TUNE_CACHE[key] < WINO or extra:
+                    return _TUNE_CACHE[key]
+                keep = False             # a cached Winograd choice with Winograd plans switched off: time the direct plans,
+                                         # leave the cache entry alone
             best, best_t = 0, None
             # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
             # deep K splits put every CU on the weight stream
@@ -528,7 +614,8 @@ class Plan(object):
                 t = min(ts)
                 if best_t is None or t < best_t * 0.985:     # prefer earlier (simpler) candidates on near-ties
                     best, best_t = code, t
-            _TUNE_CACHE[key] = best
+            if keep:
+                _TUNE_CACHE[key] = best
             return best
 
         def admitted(code, key, launch, out_of, operands, bn_of=None, prep=None):
@@ -989,7 +1076,10 @@ class Plan(object):
                     out_grads[id(cs.conv.bias)] = db
                 side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
                 gw = gview(cs.conv.weight, cs.packed)
-                if cs.packed:       # accumulate in place: the gradient has the parameter's channels-last layout
+                if cs.packed and getattr(cs, 'wgrad_wino', False) and self.ws_wgrad is not None:
+                    call('ssp_conv_wgrad_wino', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
+                         cs.inp.ld, self.ws_wgrad.data_ptr(), self.ws_wgrad.numel(), st2)
+                elif cs.packed:       # accumulate in place: the gradient has the parameter's channels-last layout
                     call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
                          cs.inp.ld, cs.k, st2)
                 else:

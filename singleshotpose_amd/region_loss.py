@@ -124,7 +124,14 @@ class _RegionLossBase(nn.Module):
             # calls ago: normally long finished, so this returns at once; a caller hopping streams is ordered by the wait
             slot['events'][i].synchronize()
         t1 = time.perf_counter()
-        slot['pin'][i].copy_(host_tensor)
+        # numpy's memcpy, not Tensor.copy_: ATen splits a 537 KB host-to-host copy over its intra-op thread pool, and on a
+        # 256-thread host one call in ~60-100 then waits 80-95 ms for a parked worker (tools/label_upload_probe.py,
+        # profiles/r03_label_upload.json: the whole stall sits in this one statement) - one thread copies it in ~30 us
+        np_pin = slot.get('pin_np')
+        if np_pin is None:
+            np_pin = slot['pin_np'] = [t.numpy() for t in slot['pin']]
+        import numpy as np
+        np.copyto(np_pin[i], host_tensor.numpy())
         t2 = time.perf_counter()
         if self.label_upload == 'mapped':
             # pinned host memory is mapped into the GPU's address space: the kernel reads the labels (<= 269 KB, one pass)

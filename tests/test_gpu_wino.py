@@ -108,8 +108,9 @@ def test_wino_conv_fwd_affine_eval_block():
     wsn = _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, WINO)
     ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
     out = torch.empty(B * H * W, Cout, dtype=torch.float32, device=G.dev())
-    _lib.call('ssp_conv_fwd_affine', xd.data_ptr(), U.data_ptr(), out.data_ptr(), sc.to(G.dev()).data_ptr(),
-              sh.to(G.dev()).data_ptr(), 0.1, B, H, W, Cin, Cout, Cin, Cout, 3, WINO, ws.data_ptr(), wsn, G.stream())
+    scd, shd = sc.to(G.dev()), sh.to(G.dev())
+    _lib.call('ssp_conv_fwd_affine', xd.data_ptr(), U.data_ptr(), out.data_ptr(), scd.data_ptr(), shd.data_ptr(), 0.1, B, H, W,
+              Cin, Cout, Cin, Cout, 3, WINO, ws.data_ptr(), wsn, G.stream())
     torch.cuda.synchronize()
     assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
 
@@ -165,6 +166,39 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout):
     s1, s2 = dyp.sum(dim=(0, 2, 3)), (dyp * xhat).sum(dim=(0, 2, 3))
     got = part.view(rows, Cin, 2).double().sum(dim=0).cpu()
     assert rel_err(got[:, 0].numpy(), s1.numpy()) < TOL and rel_err(got[:, 1].numpy(), s2.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 13, 13, 128, 256), (3, 10, 14, 256, 64), (64, 13, 13, 256, 512), (16, 7, 9, 64, 192)])
+def test_wino_conv_wgrad(B, H, W, Cin, Cout):
+    """Filter gradient in the Winograd domain (ssp_conv_wgrad_wino) against autograd of F.conv2d and against the direct
+    kernel; accumulates into dw (a second call doubles it)."""
+    G, _lib = _imports()
+    rs = np.random.RandomState(Cin * 5 + Cout + W)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32))
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xd, dyd = G.to_nhwc(x), G.to_nhwc(dy)
+    wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout)
+    ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+    dwp = torch.zeros(Cout * 9 * Cin, dtype=torch.float32, device=G.dev())
+
+    def unpack(buf):
+        gw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=G.dev())
+        _lib.call('ssp_unpack_grad', buf.data_ptr(), gw.data_ptr(), Cout, Cin, Cin, 3, G.stream())
+        torch.cuda.synchronize()
+        return gw.cpu().numpy()
+
+    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin,
+              ws.data_ptr(), wsn, G.stream())
+    got = unpack(dwp)
+    direct = torch.zeros_like(dwp)
+    _lib.call('ssp_conv_wgrad', dyd.data_ptr(), xd.data_ptr(), direct.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, 3, G.stream())
+    print('winograd wgrad vs autograd %.2e, vs the direct kernel %.2e' % (rel_err(got, w.grad.numpy()), rel_err(got, unpack(direct))))
+    assert rel_err(got, w.grad.numpy()) < TOL
+    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin,
+              ws.data_ptr(), wsn, G.stream())
+    assert rel_err(unpack(dwp), 2 * w.grad.numpy()) < TOL
 
 
 def test_wino_plan_on_a_shape_it_does_not_fit_is_an_error():

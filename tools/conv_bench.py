@@ -101,11 +101,16 @@ def run_cases(args, dev, st, B):
                                            coutp, Cin, R, 0, plan, ws.data_ptr(), wsn, st),
                 'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
                                            coutp, Cin, R, st),
+                'wgradw': lambda: _lib.call('ssp_conv_wgrad_wino', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
+                                            coutp, Cin, wsw.data_ptr(), wsw.numel(), st),
                 'wfilt': lambda: _lib.call('ssp_wino_filter_transform', w.data_ptr(), wf.data_ptr(), Cout, Cin, st),
             }
+            wsw = ws
+            if 'wgradw' in args.ops.split(',') and R == 3 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 64 and Cout >= 64:
+                wsw = torch.empty(_lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout), device=dev)
             line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d plan %7d |' % (name, H, Cin, Cout, R, plan)
             for op in args.ops.split(','):
-                if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])):
+                if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op in ('wgrad', 'wgradw') and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
                     continue
                 fn = fns[op]
                 for _ in range(3):

@@ -21,12 +21,11 @@ sys.path.insert(0, ROOT)
 def main():
     from singleshotpose_amd.region_loss import RegionLoss, RegionLossMulti
     dev = torch.device('cuda', 0)
-    rounds, calls = 4, 500
+    rounds, calls = 6, 500
     out = {}
     anchors = [1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018, 3.9910, 3.4879, 5.8851]
     for name, crit, ch, nlab, mode in (('single_copy', RegionLoss(), 20, 1, 'copy'), ('single_mapped', RegionLoss(), 20, 1, 'mapped'),
                                        ('single_device_labels', RegionLoss(), 20, 1, 'device'),
-                                       ('single_copy_sync_every_32', RegionLoss(), 20, 1, 'copy32'),
                                        ('multi_copy', RegionLossMulti(anchors=anchors), 160, 8, 'copy')):
         crit.verbose = False
         crit.label_upload = 'mapped' if mode == 'mapped' else 'copy'

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursiv
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for k, d in agg.items():
-    if 'conv_' not in k and 'bn_' not in k:
+    if not any(t in k for t in ('conv_', 'bn_', 'wino_', 'reduce_kernel', 'first_block')):
         continue
     fetch = d.get('FETCH_SIZE', [])
     write = d.get('WRITE_SIZE', [])
