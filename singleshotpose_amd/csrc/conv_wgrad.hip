@@ -411,7 +411,7 @@ int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B
   SSP_CHECK_ARG(ldx % 4 == 0 && ldx >= Cin && lddy % 4 == 0 && lddy >= Cout, "wgrad (Winograd): bad leading dimensions");
   SSP_CHECK_ARG((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)ws)) % 16 == 0, "wgrad (Winograd): operands must be 16-byte aligned");
   const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  SSP_CHECK_ARG(T >= 128 && T < (1ll << 31), "wgrad (Winograd): tile count out of range");
+  SSP_CHECK_ARG(T >= 16 && T < (1ll << 31), "wgrad (Winograd): tile count out of range (>= 16 tiles)");
   SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout),
                 "wgrad (Winograd): needs a workspace of %lld floats (ssp_conv_wgrad_wino_workspace_floats)",
                 (long long)ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout));

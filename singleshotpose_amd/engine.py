@@ -415,7 +415,7 @@ class Plan(object):
             cs.wgrad_wino = False
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
                     cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= 256 and
-                    self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 128):
+                    self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 16):
                 continue
             key = ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld)
             wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout)

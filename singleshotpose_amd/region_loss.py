@@ -140,8 +140,9 @@ class _RegionLossBase(nn.Module):
         else:
             slot['dev'][i].copy_(slot['pin'][i], non_blocking=True)
             out = slot['dev'][i]
-        slot['used'][i] = True
-        slot['release'] = (slot['events'][i], stream)      # recorded by forward() after the kernel that reads the labels
+        if not getattr(self, '_probe_no_events', False):      # (tools/label_upload_probe.py's diagnostic mode drops the events)
+            slot['used'][i] = True
+            slot['release'] = (slot['events'][i], stream)      # recorded by forward() after the kernel that reads the labels
         t3 = time.perf_counter()
         hist = self.__dict__.setdefault('upload_host_us', [])
         hist.append(((t3 - t0) * 1e6, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6))   # total, ring wait, host copy, H2D issue

@@ -21,14 +21,17 @@ sys.path.insert(0, ROOT)
 def main():
     from singleshotpose_amd.region_loss import RegionLoss, RegionLossMulti
     dev = torch.device('cuda', 0)
-    rounds, calls = 6, 500
+    rounds, calls = 4, 500
     out = {}
     anchors = [1.4820, 2.2412, 2.0501, 3.1265, 2.3946, 4.6891, 3.1018, 3.9910, 3.4879, 5.8851]
     for name, crit, ch, nlab, mode in (('single_copy', RegionLoss(), 20, 1, 'copy'), ('single_mapped', RegionLoss(), 20, 1, 'mapped'),
                                        ('single_device_labels', RegionLoss(), 20, 1, 'device'),
+                                       ('single_copy_no_events', RegionLoss(), 20, 1, 'noevent'),
+                                       ('single_copy_same_tensor', RegionLoss(), 20, 1, 'same'),
                                        ('multi_copy', RegionLossMulti(anchors=anchors), 160, 8, 'copy')):
         crit.verbose = False
         crit.label_upload = 'mapped' if mode == 'mapped' else 'copy'
+        crit._probe_no_events = mode == 'noevent'      # diagnostic only: the ring's reuse protection is off
         head = torch.randn(64, ch, 13, 13, device=dev, requires_grad=True)
         g = torch.Generator().manual_seed(0)
         t = torch.zeros(64, 50, 21, dtype=torch.float64)
@@ -46,7 +49,7 @@ def main():
             ts = np.empty(calls)
             for i in range(calls):
                 t0 = time.perf_counter()
-                crit(head, tgt.clone() if (i % 7 == 0 and mode != 'device') else tgt, 20)      # a fresh label tensor now and then, as a DataLoader yields
+                crit(head, tgt.clone() if (i % 7 == 0 and mode not in ('device', 'same')) else tgt, 20)      # a fresh label tensor now and then, as a DataLoader yields
                 ts[i] = (time.perf_counter() - t0) * 1e6
                 if mode == 'copy32' and i % 32 == 31:
                     torch.cuda.synchronize()
