@@ -340,6 +340,9 @@ def main():
     ap.add_argument('--timers', default='conv', choices=['conv', 'all', 'none'],
                     help='launches bracketed by HIP events INSIDE the timed region: conv = forward conv launches only '
                          '(what the roofline needs), all = every launch, none')
+    ap.add_argument('--profile-run', action='store_true',
+                    help='for runs under rocprofv3: only the warm-up and the timed steps (no per-family breakdown pass, no '
+                         'kernel-exclusive pass), so the trace holds nothing but real training steps')
     ap.add_argument('--opt', default='', help='kernel experiment knobs, name=value,... (ssp_set_option); default: none')
     args = ap.parse_args()
 
@@ -423,7 +426,10 @@ def main():
     # on the host) would otherwise add milliseconds to a family's mean.
     nb = min(args.steps, 5)
     per_step = []
-    for _ in range(nb):
+    if args.profile_run:
+        per_step = [collect()]
+        per_step[0] = ([0.0] * nk, [0.0] * nk, [0] * nk)
+    for _ in range(0 if args.profile_run else nb):
         _lib.call('ssp_prof_enable', -1)
         loss = step()
         barrier()
@@ -438,8 +444,8 @@ def main():
     # each other's events: that pair is `roofline_bwd`).  Untimed, after the measurement; same operands, same plans.
     for plan in model._plans.values():
         plan.serial_backward = True
-    ex_step = []
-    for _ in range(3):
+    ex_step = [([0.0] * nk, [0.0] * nk, [0] * nk)] if args.profile_run else []
+    for _ in range(0 if args.profile_run else 3):
         _lib.call('ssp_prof_enable', 0b110)
         loss = step()
         barrier()

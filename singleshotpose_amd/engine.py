@@ -414,7 +414,8 @@ class Plan(object):
         for cs in self.convs.values():
             cs.wgrad_wino = False
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
-                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= 256 and
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and
+                    min(cs.cin, cs.cout) >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '256')) and
                     self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 16):
                 continue
             key = ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld)
@@ -560,10 +561,11 @@ class Plan(object):
         # transforms cost more than the GEMM saves on the wide maps with few channels).  SSP_WINOGRAD=0 turns them off.
         wino_cands = (WINO + 6413, WINO + 6414, WINO + 12813, WINO + 12814)
         wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
+        wino_min = int(os.environ.get('SSP_WINO_MIN_CHANNELS', '256'))
 
         def wino_ok(cs, which):
             return (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
-                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= 256)
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= wino_min)
         def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x4 mid, none big)
             mc = cs.M * max(cs.coutp, cs.cinp)
             need = 9 * mc if mc <= (1 << 21) else (4 * mc if mc <= (1 << 25) else 1)

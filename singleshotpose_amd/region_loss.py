@@ -130,8 +130,11 @@ class _RegionLossBase(nn.Module):
         np_pin = slot.get('pin_np')
         if np_pin is None:
             np_pin = slot['pin_np'] = [t.numpy() for t in slot['pin']]
-        import numpy as np
-        np.copyto(np_pin[i], host_tensor.numpy())
+        if getattr(self, '_probe_aten_staging', False):      # tools/label_upload_probe.py: the round-2 form, for the record
+            slot['pin'][i].copy_(host_tensor)
+        else:
+            import numpy as np
+            np.copyto(np_pin[i], host_tensor.numpy())
         t2 = time.perf_counter()
         if self.label_upload == 'mapped':
             # pinned host memory is mapped into the GPU's address space: the kernel reads the labels (<= 269 KB, one pass)

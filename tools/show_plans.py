@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Prints the autotuned igemm plan of every conv launch of cfg/yolo-pose.cfg at a given batch / size
-(plan code = tail*100000 + tile_rows*100 + ksplit*10 + ring_slots; 0 = library heuristic)."""
+(plan code = tail*100000 + tile_rows*100 + ksplit*10 + ring_slots; 0 = library heuristic; 9xxxxxx = Winograd)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,4 +13,5 @@ x = torch.rand(B, 3, S, S, device='cuda')
 m(x).sum().backward()
 plan = list(m._plans.values())[0]
 for ind, cs in sorted(plan.convs.items()):
-    print('layer %2d  %4dx%-4d %4d->%-4d k%d  fwd %6d  dgrad %6d' % (ind, cs.H, cs.W, cs.cin, cs.cout, cs.k, cs.plan_fwd, cs.plan_dgrad))
+    print('layer %2d  %4dx%-4d %4d->%-4d k%d  fwd %7d  dgrad %7d  wgrad %s' % (ind, cs.H, cs.W, cs.cin, cs.cout, cs.k, cs.plan_fwd, cs.plan_dgrad,
+                                                                              'winograd' if getattr(cs, 'wgrad_wino', False) else 'direct'))
