@@ -415,7 +415,7 @@ class Plan(object):
             cs.wgrad_wino = False
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
                     cs.cin % 16 == 0 and cs.cout % 16 == 0 and
-                    min(cs.cin, cs.cout) >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '256')) and
+                    min(cs.cin, cs.cout) >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128')) and
                     self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 16):
                 continue
             key = ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld)
@@ -557,11 +557,12 @@ class Plan(object):
         if not elig:
             return
         # Winograd F(2x2, 3x3) candidates (csrc/conv_wino.hip): 16/36 of the multiplies at the price of two HBM-bound
-        # transform passes - timed against the direct plans on the 3x3 layers with >= 256 channels on both sides (the
-        # transforms cost more than the GEMM saves on the wide maps with few channels).  SSP_WINOGRAD=0 turns them off.
+        # transform passes - timed against the direct plans on the 3x3 layers with >= 128 channels on both sides (with 64
+        # the tuner never picked one: the transforms of the wide maps cost more than the short-K GEMMs save; measured,
+        # profiles/r03_step_ab_winograd.txt).  SSP_WINOGRAD=0 turns them off, SSP_WINO_MIN_CHANNELS moves the threshold.
         wino_cands = (WINO + 6413, WINO + 6414, WINO + 12813, WINO + 12814)
         wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
-        wino_min = int(os.environ.get('SSP_WINO_MIN_CHANNELS', '256'))
+        wino_min = int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128'))
 
         def wino_ok(cs, which):
             return (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
