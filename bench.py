@@ -293,6 +293,8 @@ def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
             return (time.perf_counter() - t0) * 1e3
 
         keep = dict(engine._TUNE_CACHE), set(engine._TUNE_VERIFIED)
+        cache_file, engine._TUNE_CACHE_FILE[0] = engine._TUNE_CACHE_FILE[0], None     # the experiment must not rewrite SSP_TUNE_CACHE
+        os.environ.pop('SSP_TUNE_CACHE', None) if cache_file else None
         engine._TUNE_CACHE.clear()
         engine._TUNE_VERIFIED.clear()
         cold = first_visit()
@@ -309,6 +311,9 @@ def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
         dt = (time.perf_counter() - t0) / steps
         engine._TUNE_CACHE.update(keep[0])
         engine._TUNE_VERIFIED.update(keep[1])
+        if cache_file:
+            os.environ['SSP_TUNE_CACHE'] = cache_file
+            engine._TUNE_CACHE_FILE[0] = cache_file
         flop = 87.673e9 * (size / 416.0) ** 2
         plan = next(iter(model._plans.values()))
         out['train_%d_b%d' % (size, B)] = {

@@ -10,11 +10,14 @@ rm -f $SSP_TUNE_CACHE
 REPO=$(pwd)
 timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err
+# (profiled runs: tuned choices come from the bench run's cache, already verified there - no verify launches in the traces)
+export SSP_TUNE_VERIFY=0
 cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-extras --profile-run > $REPO/gpurun_out/prof_$TAG.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_traffic_$TAG/$C -o p -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-extras --profile-run > $REPO/gpurun_out/pmc_traffic_$TAG/$C.log 2>&1
 done
 cd $REPO
+unset SSP_TUNE_VERIFY
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && cp "$F" gpurun_out/kernel_stats_$TAG.csv && head -24 "$F" | cut -c1-170
 python tools/timeline.py $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1) > gpurun_out/timeline_$TAG.txt 2>&1
