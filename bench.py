@@ -98,6 +98,12 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=30.0, big_batch=64):
     (64) is timed at the two largest counts only (one warm-up + one step each: ~7 s per step)."""
     all_threads = torch.get_num_threads()
     ncpu = os.cpu_count() or all_threads
+    quota = None          # CPU-bandwidth limit of this container (cgroup v2 cpu.max "quota period"): the cores a step can really use
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota = None if q == 'max' else round(float(q) / float(per), 2)
+    except Exception:
+        pass
     cands = sorted(set(t for t in (8, 16, 32, 64, all_threads) if t <= max(all_threads, 8)))
     t_begin = time.time()
     ref = _reference_times(cfgfile, B, H, cands)
@@ -111,7 +117,8 @@ def cpu_baseline(cfgfile, B, H, W, budget_s=30.0, big_batch=64):
                          "steps of fwd+RegionLoss+bwd at batch %d, %dx%d with %d threads - the fastest of a one-step sweep "
                          "over %s threads" % (B, H, W, best, sorted(sweep)),
                "modules": ref['modules'],
-               "sweep_images_per_s": {str(k): round(B / v, 3) for k, v in sorted(sweep.items())}, "host_cpus": ncpu}
+               "sweep_images_per_s": {str(k): round(B / v, 3) for k, v in sorted(sweep.items())}, "host_cpus": ncpu,
+               "cgroup_cpu_quota_cores": quota}
         if big_batch and big_batch != B and time.time() - t_begin < budget_s + 30:
             big = _reference_times(cfgfile, big_batch, H, sorted(set(cands[-2:])), timeout=300)
             if big is not None:
