@@ -43,7 +43,7 @@ int ssp_set_option(const char* name, int value);
  *   tail 0 or 2..9 = hybrid launch: whole resident waves un-split, the last partial wave's tiles split `tail` ways);
  * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
  * models) may run different plans concurrently.  The same code must be passed to the two queries.
- *   9000000 + tile_rows*100 + 10 + ring_slots = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout > 64
+ *   9000000 + tile_rows*100 + 10 + ring_slots (3|4|8) = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout > 64
  *   and % 4 == 0; conv_wino.hip): same result to ~1e-6 of its range with 16/36 of the multiplies.  `wt` must then be the
  *   TRANSFORMED filter from ssp_wino_filter_transform (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the workspace
  *   (ssp_conv_workspace_floats: 16 * tiles * (Cin + Cout) floats) is mandatory; a Winograd code on a shape it does not
@@ -92,7 +92,9 @@ int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int
 /* The same filter gradient of a 3x3 layer (Cin, Cout >= 64 and % 16 == 0) evaluated in the Winograd F(2x2, 3x3) domain
  * (csrc/conv_wino.hip): dw += the direct result to ~1e-6 of its range with 16/36 of the multiplies.  dw must be 16-byte
  * aligned, [Cout][3][3][Cin] floats (the ssp_repack_fwd layout), written by this launch alone while it runs;
- * workspace: ssp_conv_wgrad_wino_workspace_floats(...) floats. */
+ * workspace: ssp_conv_wgrad_wino_workspace_floats(...) floats.  x == NULL: the transformed input V is already at the head
+ * of the workspace - left there by this layer's ssp_conv_fwd with a Winograd plan and the SAME workspace buffer (both
+ * layouts start with V [16][tiles][Cin]) - so the layer input is transformed once per training step, not twice. */
 int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout);
 int ssp_conv_wgrad_wino(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                         int ldx, float* workspace, int64_t workspace_floats, void* stream);

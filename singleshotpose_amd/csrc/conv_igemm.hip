@@ -550,7 +550,7 @@ static int wino_launch(ConvArgs& a, int B, int H, int W, float* ws, int64_t ws_f
   const int bm = (plan / 100) % 1000, slots = plan % 10;
   SSP_CHECK_ARG(a.R == 3 && a.Cin % 16 == 0 && a.Cout > 64 && a.Cout % 4 == 0 && a.ldout % 4 == 0 && (((uintptr_t)a.out) & 15) == 0,
                 "conv (Winograd plan): needs a 3x3 filter, Cin %% 16 == 0, Cout > 64 and %% 4 == 0, an aligned output");
-  SSP_CHECK_ARG((bm == 64 || bm == 128) && (slots == 3 || slots == 4) && (plan / 10) % 10 == 1, "conv: bad Winograd plan code %d", plan);
+  SSP_CHECK_ARG((bm == 64 || bm == 128) && (slots == 3 || slots == 4 || slots == 8) && (plan / 10) % 10 == 1, "conv: bad Winograd plan code %d", plan);
   const int64_t T = ssp_wino_tiles(B, H, W);
   SSP_CHECK_ARG(T < (1ll << 31) && 16 * T * (int64_t)a.Cin < (1ll << 40), "conv (Winograd plan): too many tiles");
   SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_wino_ws_floats(B, H, W, a.Cin, a.Cout) && (((uintptr_t)ws) & 15) == 0,

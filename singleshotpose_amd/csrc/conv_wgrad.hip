@@ -400,7 +400,9 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
 // Filter gradient of a 3x3 layer in the Winograd domain (conv_wino.hip): transform the input (B^T d B) and the output
 // gradient (A dY A^T) into 16 planes each, contract the planes pairwise over the tiles in ONE batched launch of the
 // LDS-direct filter-gradient kernel, map the 16 results back onto the 9 taps (G^T . G) and add them to dw.
-// workspace: V [16][T][Cin] | dM [16][T][Cout] | dU [16][Cout][Cin] (ssp_conv_wgrad_wino_ws_floats).
+// workspace: V [16][T][Cin] | dM [16][T][Cout] | dU [16][Cout][Cin] (ssp_conv_wgrad_wino_ws_floats); V sits where a
+// Winograd forward launch puts it (workspace head), so a caller that hands both launches the same buffer transforms the
+// layer input once per step.
 int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout) {
   const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
   return 16 * (T * ((int64_t)Cin + Cout) + (int64_t)Cin * Cout);
@@ -419,7 +421,10 @@ int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B
   float* V = ws;
   float* dM = V + 16 * T * Cin;
   float* dU = dM + 16 * T * Cout;
-  if (int rc = ssp_wino_input_launch(x, ldx, V, B, H, W, Cin, stream)) return rc;
+  // x == nullptr: the transformed input is already at the head of the workspace - the forward launch of the same layer
+  // (a Winograd plan of ssp_conv_fwd given THIS workspace) left V there, and nothing has written the region since
+  if (x != nullptr)
+    if (int rc = ssp_wino_input_launch(x, ldx, V, B, H, W, Cin, stream)) return rc;
   if (int rc = ssp_wino_outgrad_launch(dy, lddy, dM, B, H, W, Cout, stream)) return rc;
   if (hipMemsetAsync(dU, 0, (size_t)16 * Cin * Cout * 4, stream) != hipSuccess) {
     ssp_set_error("wgrad (Winograd): hipMemsetAsync failed");

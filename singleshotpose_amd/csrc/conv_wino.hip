@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) transforms for the deep 3x3 layers (the 13x13 / 26x26 maps with >= 256 channels).
+// Winograd F(2x2, 3x3) transforms for the deep 3x3 layers (the 13x13 ... 52x52 maps with >= 128 channels).
 //
 // The fp32 MFMA is the binding resource of the training step (conv_igemm_dma.hip runs it 88 - 93 % busy), and on gfx950 it
 // has no faster fp32 form - so the remaining lever on those layers is arithmetic: a 3x3 stride-1 convolution evaluated on

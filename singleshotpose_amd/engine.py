@@ -318,7 +318,6 @@ class Plan(object):
         self.grad_total = goff
         self.reducer = None      # singleshotpose_amd.dist.GradReducer (multi-GPU): notified as layers finish
         self.side_stream = None
-        self.ws_wgrad = None           # workspace of the Winograd-domain filter gradients (they run on the side stream)
         self.serial_backward = False   # measurement aid (bench.py): filter gradients on the MAIN stream, so that every
                                        # backward launch runs alone and its HIP-event duration is kernel-exclusive
         self.dgrad_ready = None
@@ -360,6 +359,18 @@ class Plan(object):
         if getattr(cs, 'wino_ud', None) is None:
             cs.wino_ud = torch.empty(16 * cs.cin * cs.coutp, dtype=torch.float32, device=self.device)
         return cs.wino_ud
+
+    def _wino_ws(self, cs):
+        """Per-layer Winograd workspace of a layer whose FILTER GRADIENT runs in the Winograd domain (V | dM | dU, on the
+        side stream).  When the layer's forward plan is a Winograd code too, the training forward is handed this same
+        buffer (V | M): the transformed input V it leaves at the head is what the filter gradient needs, so the layer
+        input is transformed once per step (csrc/conv_wgrad.hip ssp_conv_wgrad_wino_launch, x == NULL)."""
+        if getattr(cs, 'wino_ws', None) is None:
+            n = cs.wino_ws_floats
+            if cs.plan_fwd >= WINO:
+                n = max(n, _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd))
+            cs.wino_ws = torch.empty(n, dtype=torch.float32, device=self.device)
+        return cs.wino_ws
 
     def _gbuf(self, cs):
         if getattr(cs, 'gbuf', None) is None:
@@ -472,9 +483,8 @@ class Plan(object):
                 cs.wgrad_wino = use
                 del ws, dw
             if cs.wgrad_wino:
-                need = max(need, wsn)
+                cs.wino_ws_floats = wsn
         torch.cuda.synchronize()
-        self.ws_wgrad = torch.empty(need, dtype=torch.float32, device=self.device) if need > 1 else None
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
 
@@ -687,7 +697,9 @@ class Plan(object):
 
                 if wino and key not in _TUNE_CACHE:
                     prep_f()
-                code = best_of(launch, cs.M * cs.coutp, key, wino_cands if wino else ())
+                # (small grids - batch-1 inference: also the 8-slot latency ring for the batched GEMM, as for the direct plans)
+                wc = (wino_cands + ((WINO + 6418, WINO + 12818) if cs.M * cs.coutp <= (1 << 23) else ())) if wino else ()
+                code = best_of(launch, cs.M * cs.coutp, key, wc)
                 a = cs.inp
                 cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [(a.t, a.ld, a.off % a.ld, cs.cinp)] +
                                        ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None,
@@ -859,9 +871,15 @@ class Plan(object):
                          v[3].data_ptr() if cs.bn else bias, cs.slope, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld,
                          cs.out.ld, cs.k, cs.plan_fwd, self.ws.data_ptr(), self.ws_floats, st)
                     continue
+                ws_t = self.ws
+                cs.v_live = False
+                if (need_grad and cs.plan_fwd >= WINO and getattr(cs, 'wgrad_wino', False) and
+                        os.environ.get('SSP_WINO_SHARE_V', '1') != '0'):
+                    ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
+                    cs.v_live = True
                 call('ssp_conv_fwd', cs.inp.ptr, wptr, cs.raw.data_ptr(), bias,
                      cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
-                     cs.k, 0, cs.plan_fwd, self.ws.data_ptr(), self.ws_floats, st)
+                     cs.k, 0, cs.plan_fwd, ws_t.data_ptr(), ws_t.numel(), st)
                 if cs.bn and training:
                     bn = cs.bnm
                     call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
@@ -1079,9 +1097,11 @@ class Plan(object):
                     out_grads[id(cs.conv.bias)] = db
                 side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
                 gw = gview(cs.conv.weight, cs.packed)
-                if cs.packed and getattr(cs, 'wgrad_wino', False) and self.ws_wgrad is not None:
-                    call('ssp_conv_wgrad_wino', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
-                         cs.inp.ld, self.ws_wgrad.data_ptr(), self.ws_wgrad.numel(), st2)
+                if cs.packed and getattr(cs, 'wgrad_wino', False):
+                    wws = self._wino_ws(cs)
+                    call('ssp_conv_wgrad_wino', dy_ptr, None if getattr(cs, 'v_live', False) else cs.inp.ptr, gw.data_ptr(),
+                         B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld, cs.inp.ld, wws.data_ptr(), wws.numel(), st2)
+                    cs.v_live = False
                 elif cs.packed:       # accumulate in place: the gradient has the parameter's channels-last layout
                     call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
                          cs.inp.ld, cs.k, st2)

@@ -201,6 +201,34 @@ def test_wino_conv_wgrad(B, H, W, Cin, Cout):
     assert rel_err(unpack(dwp), 2 * w.grad.numpy()) < TOL
 
 
+def test_wino_wgrad_reuses_the_forward_launch_transformed_input():
+    """ssp_conv_wgrad_wino with x == NULL: the transformed input V left at the head of the workspace by the layer's own
+    Winograd forward launch (same buffer) is used instead of transforming x again - same gradient as with x."""
+    G, _lib = _imports()
+    B, H, W, Cin, Cout = 8, 13, 13, 128, 256
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32))
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xd, dyd = G.to_nhwc(x), G.to_nhwc(dy)
+    wd = G.pack_fwd(w.detach())
+    U = _wino_filters(G, _lib, wd, Cout, Cin)
+    wsn = max(_lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout),
+              _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, WINO))
+    ws = torch.full((wsn,), float('nan'), dtype=torch.float32, device=G.dev())
+    out = torch.empty(B * H * W, Cout, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_conv_fwd', xd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout, Cin, Cout, 3, 0, WINO,
+              ws.data_ptr(), wsn, G.stream())
+    dwp = torch.zeros(Cout * 9 * Cin, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), None, dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, ws.data_ptr(), wsn,
+              G.stream())
+    gw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_unpack_grad', dwp.data_ptr(), gw.data_ptr(), Cout, Cin, Cin, 3, G.stream())
+    torch.cuda.synchronize()
+    assert rel_err(gw.cpu().numpy(), w.grad.numpy()) < TOL
+
+
 def test_wino_plan_on_a_shape_it_does_not_fit_is_an_error():
     G, _lib = _imports()
     x = torch.zeros(4 * 4 * 4, 64, device=G.dev())
