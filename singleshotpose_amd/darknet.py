@@ -201,10 +201,17 @@ class Darknet(nn.Module):
             # forward buffers now, gradient buffers of about the same size on the first backward
             # (counted from the plan's own tensors: an allocator delta is wrong whenever the garbage collector frees another
             # model's buffers while the plan is being built)
-            plan.nbytes_est = 2 * plan.footprint()
+            # (x2.5: gradient buffers of the same size, plus the Winograd operands / per-layer workspaces the tuner may add)
+            plan.nbytes_est = int(2.5 * plan.footprint())
             budget = self._plan_mem_frac * torch.cuda.get_device_properties(device).total_memory
-            while self._plans and plan.nbytes_est + sum(p.nbytes_est for p in self._plans.values()) > budget:
+            evicted = False
+            # cached plans are charged what they hold NOW (their backward and Winograd buffers exist by then)
+            while self._plans and plan.nbytes_est + sum(max(p.nbytes_est, p.nbytes_now()) for p in self._plans.values()) > budget:
                 self._plans.popitem(last=False)
+                evicted = True
+            if evicted:
+                torch.cuda.empty_cache()      # hand the evicted plans' blocks back: the caching allocator would keep them
+                                              # reserved next to the new plan's (a 20-shape batch-64 schedule reached 245 GB)
             red = getattr(self, '_reducer', None)
             plan.reducer = red if (red is not None and red.active) else None
             self._plans[key] = plan

@@ -342,6 +342,25 @@ class Plan(object):
                 total += t.numel() * t.element_size()
         return total
 
+    def nbytes_now(self):
+        """Bytes of device memory the plan holds right now: forward buffers, and whatever the first backward and the tuner
+        added since (gradient buffers, data-gradient operands, Winograd filters and per-layer workspaces)."""
+        seen, total = set(), 0
+        ts = [self.x_nhwc, self.ws, self.bn_partial, self._dpack] + [a.t for a in self.acts if a is not None]
+        ts += [g.t for g in self.grads.values()]
+        for cs in self.convs.values():
+            ts += [cs._raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None), getattr(cs, 'wbuf', None),
+                   getattr(cs, 'gbuf', None), getattr(cs, 'wino_u', None), getattr(cs, 'wino_ud', None),
+                   getattr(cs, 'wino_ws', None)]
+            bnp = getattr(cs, 'bnp', None)
+            if bnp is not None:
+                ts.append(bnp[0])
+        for t in ts:
+            if t is not None and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+        return total
+
     # ------------------------------------------------------------------ lazily allocated filter staging
     def _wbuf(self, cs):
         if getattr(cs, 'wbuf', None) is None:
