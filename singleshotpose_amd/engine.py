@@ -437,7 +437,6 @@ class Plan(object):
         st = torch.cuda.current_stream().cuda_stream
         wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
         verify = os.environ.get('SSP_TUNE_VERIFY', '1') != '0'
-        need = 1
         gen = torch.Generator(device=self.device)
         gen.manual_seed(4321)
         n_known = len(_TUNE_CACHE)
