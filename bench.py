@@ -301,7 +301,8 @@ def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
 
         keep = dict(engine._TUNE_CACHE), set(engine._TUNE_VERIFIED)
         cache_file, engine._TUNE_CACHE_FILE[0] = engine._TUNE_CACHE_FILE[0], None     # the experiment must not rewrite SSP_TUNE_CACHE
-        os.environ.pop('SSP_TUNE_CACHE', None) if cache_file else None
+        if cache_file:
+            os.environ.pop('SSP_TUNE_CACHE', None)
         engine._TUNE_CACHE.clear()
         engine._TUNE_VERIFIED.clear()
         cold = first_visit()

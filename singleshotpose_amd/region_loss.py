@@ -11,6 +11,10 @@ region_loss.py:9-78) and uploads 23 mask/target tensors.  Here ssp_region_loss d
 loss + dL/d(output) in one launch per call; the only host traffic is the (<= 269 KB) label upload and - when
 `verbose` - one 32-byte read of the scalars for the status line.
 """
+import os
+import time
+
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -94,7 +98,6 @@ class _RegionLossBase(nn.Module):
         self.verbose = True      # print the reference's status line (one 32-byte device read per call)
         # host labels reach the kernel through a pinned ring: 'copy' = asynchronous copy into a device twin, 'mapped' = the
         # kernel reads the pinned buffer in place (zero copy)
-        import os
         self.label_upload = os.environ.get('SSP_LABEL_UPLOAD', 'copy')
         self._last_stats = None
 
@@ -105,7 +108,6 @@ class _RegionLossBase(nn.Module):
         all created once per (shape, dtype, device): a call is one host memcpy into the pinned slot, one asynchronous
         copy in stream order, one event record - no allocation (host, device or event) after the first lap of the ring.
         `upload_host_us` keeps the host time of the last calls (tools/label_upload_probe.py, tests/test_gpu_head.py)."""
-        import time
         t0 = time.perf_counter()
         key = (tuple(host_tensor.shape), host_tensor.dtype, str(device))
         ring = self.__dict__.setdefault('_pin_ring', {})
@@ -133,7 +135,6 @@ class _RegionLossBase(nn.Module):
         if getattr(self, '_probe_aten_staging', False):      # tools/label_upload_probe.py: the round-2 form, for the record
             slot['pin'][i].copy_(host_tensor)
         else:
-            import numpy as np
             np.copyto(np_pin[i], host_tensor.numpy())
         t2 = time.perf_counter()
         if self.label_upload == 'mapped':
