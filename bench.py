@@ -373,7 +373,10 @@ def main():
     from singleshotpose_amd.optim import SGD
     from singleshotpose_amd.region_loss import RegionLoss
 
-    if world > 1:
+    # SSP_BENCH_FORCE_REDUCER=1: run the collective path (process group, bucketed all-reduce from the filter-gradient
+    # stream, `comm` diagnostics) on ONE rank - a rehearsal of everything the N > 1 run does except the second GPU
+    dist_on = world > 1 or os.environ.get('SSP_BENCH_FORCE_REDUCER') == '1'
+    if dist_on:
         init_distributed()
     for kv in filter(None, args.opt.split(',')):
         name, val = kv.split('=')
@@ -388,7 +391,7 @@ def main():
     # the reference's sum-loss convention (train.py:45,388): lr / batch, decay * batch with the GLOBAL batch
     # torch.optim.SGD's update rule (train.py:388) as one fused launch over the flat parameter/gradient/momentum buffers
     opt = SGD(model.parameters(), lr=1e-3 / global_batch, momentum=0.9, dampening=0, weight_decay=0.0005 * global_batch)
-    reducer = GradReducer(model, world)
+    reducer = GradReducer(model, world, force=dist_on and world == 1)
     x, tgt = synthetic_batch(B, H, W, 1000 + rank, device)
 
     def step():
@@ -401,7 +404,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -468,7 +471,7 @@ def main():
         plan.serial_backward = False
     ex = {k: (float(np.median([p[0][k] for p in ex_step])), float(np.median([p[1][k] for p in ex_step])),
               float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2)}
-    if world > 1:
+    if dist_on:
         # communication diagnostics (untimed): per-bucket all-reduce issue -> done times and the exposed tail of one step
         reducer.profile = True
         loss = step()
@@ -583,7 +586,7 @@ def main():
             "verified": verified,
             "verify": verify_detail,
         }
-        if world > 1:
+        if dist_on:
             res["comm"] = comm
         if world == 1 and not args.no_extras:
             del opt, x
@@ -593,9 +596,20 @@ def main():
             res["extra"].update(multiscale_extras(device))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cfg, args.cpu_batch, H, W)
-        print(json.dumps(res))
-    if world > 1:
+    else:
+        res = None
+    if dist_on:
         torch.distributed.destroy_process_group()
+    if res is not None:
+        # ONE JSON line, and the LAST line of stdout: RCCL writes its version banner through C stdio, which would otherwise
+        # flush at exit - after this line
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
