@@ -478,7 +478,7 @@ def main():
         barrier()
         reducer.profile = False
         comm = reducer.report()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:

@@ -75,7 +75,7 @@ def main():
                             p99=round(float(np.percentile(ms, 99)), 3), max=round(float(ms.max()), 3),
                             first_100_mean=round(float(ms[:100].mean()), 3), last_100_mean=round(float(ms[-100:].mean()), 3)),
                per_100_steps_ms=[round(float(ms[i:i + 100].mean()), 3) for i in range(0, N, 100)],
-               sclk_mhz=clocks, final_loss=float(loss),
+               sclk_mhz=clocks, final_loss=float(loss.detach()),
                memory_mb=dict(allocated_before=round(a0 / 1e6, 1), allocated_after=round(a1 / 1e6, 1),
                               reserved_before=round(r0 / 1e6, 1), reserved_after=round(r1 / 1e6, 1)))
     print(json.dumps(rec))

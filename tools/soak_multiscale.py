@@ -55,7 +55,7 @@ def main():
         dt = time.perf_counter() - t0
         steady = (dt - first) / max(per - 1, 1)
         peak = max(peak, torch.cuda.memory_reserved())
-        l = float(loss)
+        l = float(loss.detach())
         assert l == l, "loss became NaN at visit %d (size %d)" % (v, size)
         rec.append(dict(visit=v, size=size, new_shape=new, first_step_ms=round(first * 1e3, 1), steady_ms=round(steady * 1e3, 2),
                         images_per_s=round(B / steady, 1), plans_cached=len(m._plans),
