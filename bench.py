@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0           # HBM3E, MI355X_MICROARCH.md (~6.3 TB/s achievable)
 
 
 def synthetic_batch(B, H, W, seed, device):
@@ -182,6 +183,27 @@ def forward_traffic_per_launch():
     return (round(tot / n) if n else None), src
 
 
+def wino_traffic_per_step():
+    """Fabric bytes per training step of the Winograd transform / finishing kernels, from the committed PMC passes
+    (profiles/r*_traffic.json: launches there cover `steps_profiled` steps), or None when the kernels changed since."""
+    import glob
+    from singleshotpose_amd._lib import csrc_digest
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    src = os.path.relpath(files[-1], ROOT)
+    meta = data.pop('_meta', {})
+    if meta.get('csrc_sha1') != csrc_digest():
+        return None, "%s is stale: kernels changed since it was taken" % src
+    steps = float(meta.get('steps_profiled', 2))
+    tot = 0.0
+    for name, v in data.items():
+        if name.startswith('wino_') and 'wino_filter' not in name:
+            tot += v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch_reported'])
+    return round(tot / steps), src
+
+
 def verify_step(model, crit, B, H, W, seed, exact=False):
     """One training step of THIS model on THIS batch against the CPU oracle (oracle/step_check.py), before anything is
     timed: head / loss / running statistics vs an independent oracle forward, every conv launch vs the oracle's
@@ -252,6 +274,24 @@ def extras(device, steps=5):
                                    "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1)}
     del model, opt
     torch.cuda.empty_cache()
+    # the shipped cfg's own batch (yolo-pose.cfg:3, what the reference's unmodified train.py runs): launch- / ramp-bound
+    from singleshotpose_amd.region_loss import RegionLoss
+    torch.manual_seed(0)
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).to(device).train()
+    crit1 = RegionLoss()
+    crit1.verbose = False
+    opt = SGD(model.parameters(), lr=1e-3 / 8, momentum=0.9, dampening=0, weight_decay=0.0005 * 8)
+    x8, t8 = synthetic_batch(8, 416, 416, 77, device)
+
+    def step8():
+        opt.zero_grad(set_to_none=True)
+        crit1(model(x8), t8, 20).backward()
+        opt.step()
+    dt = timed(step8, 20, warm=3)
+    out['train_416_b8'] = {"workload": "cfg/yolo-pose.cfg train step, 416x416, batch 8 (the cfg's own batch)",
+                           "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(8 / dt, 1)}
+    del model, opt, x8
+    torch.cuda.empty_cache()
     model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).to(device).eval()
     with torch.no_grad():
         for b, n in ((1, 30), (64, 5)):
@@ -299,7 +339,7 @@ def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) * 1e3
 
-        keep = dict(engine._TUNE_CACHE), set(engine._TUNE_VERIFIED)
+        keep = dict(engine._TUNE_CACHE), dict(engine._TUNE_VERIFIED)
         cache_file, engine._TUNE_CACHE_FILE[0] = engine._TUNE_CACHE_FILE[0], None     # the experiment must not rewrite SSP_TUNE_CACHE
         if cache_file:
             os.environ.pop('SSP_TUNE_CACHE', None)
@@ -327,7 +367,7 @@ def multiscale_extras(device, B=64, sizes=(224, 608, 832), steps=4):
         out['train_%d_b%d' % (size, B)] = {
             "workload": "cfg/yolo-pose.cfg train step, %dx%d, batch %d" % (size, size, B),
             "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1),
-            "step_conv_flop_frac_of_peak": round(B / dt * flop / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "step_conv_effective_flop_frac_of_peak": round(B / dt * flop / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "first_visit_ms": {"cold_tune_cache": round(cold, 1), "warm_tune_cache_unverified": round(warm_file, 1),
                                "warm_tune_cache_verified": round(rebuilt, 1)},
             "tuned_launches": sum(1 for cs in plan.convs.values() if cs.plan_fwd or cs.plan_dgrad)}
@@ -408,6 +448,34 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    grad_check = None
+    if dist_on:
+        # SURVEY.md 8(d) config 3, untimed: every rank runs the SAME batch (same seed, same initial weights), once with the
+        # reducer standing aside and once through it - the reduced flat gradient must be world x the local one (<= 1e-5 of
+        # its range; the filter-gradient kernels' fp32 atomics make two evaluations differ in the last bits)
+        x0, t0_ = synthetic_batch(B, H, W, 1000, device)
+        reducer.enabled = False
+        opt.zero_grad(set_to_none=True)
+        crit(model(x0), t0_, 20).backward()
+        plan_ = next(iter(model._plans.values()))
+        local = plan_.last_flat_grad.clone()
+        reducer.enabled = True
+        for p_ in model._plans.values():
+            p_.reducer = reducer if reducer.active else None
+        opt.zero_grad(set_to_none=True)
+        crit(model(x0), t0_, 20).backward()
+        reducer.all_reduce()
+        red_ = plan_.last_flat_grad
+        err = float((red_ - world * local).abs().max() / local.abs().max().clamp_min(1e-30))
+        errt = torch.tensor([err], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(errt, op=torch.distributed.ReduceOp.MAX)
+        grad_check = {"reduced_vs_world_x_local_rel": float(errt.item()), "bar": 1e-5, "ok": bool(errt.item() <= 1e-5),
+                      "floats": int(local.numel())}
+        assert grad_check["ok"], "reduced gradients differ from world x local gradients: %r" % (grad_check,)
+        opt.zero_grad(set_to_none=True)
+        del x0, local
+
     verified, verify_detail = None, None
     if world == 1 and not args.no_verify:
         verified, verify_detail = verify_step(model, crit, B, H, W, 1000 + rank, exact=args.verify_exact)
@@ -462,7 +530,7 @@ def main():
         plan.serial_backward = True
     ex_step = [([0.0] * nk, [0.0] * nk, [0] * nk)] if args.profile_run else []
     for _ in range(0 if args.profile_run else 3):
-        _lib.call('ssp_prof_enable', 0b110)
+        _lib.call('ssp_prof_enable', (1 << 1) | (1 << 2) | (1 << 10) | (1 << 11))      # dgrad, wgrad + their Winograd passes
         loss = step()
         barrier()
         _lib.call('ssp_prof_enable', 0)
@@ -470,7 +538,7 @@ def main():
     for plan in model._plans.values():
         plan.serial_backward = False
     ex = {k: (float(np.median([p[0][k] for p in ex_step])), float(np.median([p[1][k] for p in ex_step])),
-              float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2)}
+              float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2, 10, 11)}
     if dist_on:
         # communication diagnostics (untimed): per-bucket all-reduce issue -> done times and the exposed tail of one step
         reducer.profile = True
@@ -478,6 +546,11 @@ def main():
         barrier()
         reducer.profile = False
         comm = reducer.report()
+        comm["grad_check"] = grad_check
+        try:
+            comm["rccl_version"] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
     final_loss = float(loss.detach())
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -500,39 +573,71 @@ def main():
         traffic, traffic_src = forward_traffic_per_launch()
         images_per_s = global_batch * args.steps / dt
 
-        # `achieved` counts ALGORITHMIC FLOPs (direct convolution, 2*M*Cout*9*Cin): layers the autotuner runs in the Winograd
-        # F(2x2,3x3) domain (plan codes >= 9000000, csrc/conv_wino.hip) execute 16/36 of those multiplies (x tile padding), so
-        # their fraction of the MFMA peak can exceed 1.  `executed` is the same time against the FLOPs the matrix pipe really
-        # issued - the utilisation figure.
+        # FLOP accounting.  ALGORITHMIC = direct convolution, 2*M*Cout*k*k*Cin (what images/s converts to).
+        # EXECUTED = what the MFMA pipe really issued: a layer the autotuner runs in the Winograd F(n x n, 3x3) domain
+        # (plan codes 9xxxxxx: n = 2, 8xxxxxx: n = 4; csrc/conv_wino.hip) multiplies (n+2)^2 GEMMs of tiles x Cin x Cout,
+        # tiles = B * ceil(H/n) * ceil(W/n) - 16/36 resp. 36/144 of the direct multiplies, times the map's tile padding.
+        # Every roofline object's `achieved` / `frac` is the EXECUTED rate (a fraction of the roofline it names, never > 1);
+        # the algorithmic rate is reported next to it as `effective` (it can exceed the peak: fewer multiplies were needed).
+        from singleshotpose_amd.engine import wino_tile
         plan0 = next(iter(model._plans.values()))
         alg = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
         exe = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
-        wino_layers = {'fwd': [], 'dgrad': [], 'wgrad': []}
+        wino_layers = {f: {2: [], 4: []} for f in alg}
         for ind, cs in sorted(plan0.convs.items()):
             if cs.first:
                 continue
             direct = 2.0 * cs.M * cs.cout * cs.k * cs.k * cs.cin
-            tiles = B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2)
-            wino = 2.0 * 16 * tiles * cs.cin * cs.cout
-            for fam, on in (('fwd', cs.plan_fwd >= 9000000), ('dgrad', cs.plan_dgrad >= 9000000),
-                            ('wgrad', bool(getattr(cs, 'wgrad_wino', False)))):
+            for fam, n in (('fwd', wino_tile(cs.plan_fwd)), ('dgrad', wino_tile(cs.plan_dgrad)),
+                           ('wgrad', int(getattr(cs, 'wgrad_wino', 0) or 0))):
                 alg[fam] += direct
-                exe[fam] += wino if on else direct
-                if on:
-                    wino_layers[fam].append(ind)
+                if n:
+                    tiles = B * ((cs.H + n - 1) // n) * ((cs.W + n - 1) // n)
+                    exe[fam] += 2.0 * (n + 2) ** 2 * tiles * cs.cin * cs.cout
+                    wino_layers[fam][n].append(ind)
+                else:
+                    exe[fam] += direct
+        IGEMM = ("conv_igemm_dma_kernel<BM, BN, %d, NSLOT, WM, WN>(ConvArgs) - the instantiations rocprof lists for this "
+                 "workload: <64, 128, %d, 3|4, 2, 2> (batched Winograd GEMMs and mid-size grids), <128, 128, %d, 3, 2, 2>, "
+                 "<128, 64, %d, 3, 2, 2> (Cout <= 64), <256, 32, %d, 4, 4, 1> (Cout <= 32)")
 
-        def executed(fam, ms_):
+        def family(fam, kernel, ms_, n_, note, wino_ms=None):
+            """MFMA roofline object of one conv family: executed FLOPs / HIP-event time of its launch units (a Winograd
+            layer's transform, batched GEMM and finishing launches are one unit)."""
             tf = exe[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
-            return {"achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "flop_per_step": exe[fam],
-                    "winograd_layers": wino_layers[fam],
-                    "note": "FLOPs the MFMA pipe issued (Winograd layers: 16 GEMMs of tiles x Cin x Cout) / the same time"}
+            eff = alg[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            o = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                 "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "flop_per_step": exe[fam], "ms_per_step": round(ms_, 3), "launches_per_step": n_,
+                 "avg_launch_ms": round(ms_ / max(n_, 1), 4),
+                 "effective": {"tflops": round(eff, 2), "frac_of_peak": round(eff / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "flop_per_step": alg[fam],
+                               "note": "ALGORITHMIC (direct-convolution) FLOPs / the same time: not a roofline fraction - "
+                                       "Winograd layers need fewer multiplies than it counts"},
+                 "winograd_layers": {"F(2x2,3x3)": wino_layers[fam][2], "F(4x4,3x3)": wino_layers[fam][4]},
+                 "note": note}
+            if wino_ms is not None and ms_ > wino_ms > 0:
+                g = exe[fam] / ((ms_ - wino_ms) * 1e-3) / 1e12
+                o["gemm_kernels_only"] = {"achieved": round(g, 2), "frac": round(g / PEAK_FP32_MFMA_TFLOPS, 4),
+                                          "ms_per_step": round(ms_ - wino_ms, 3),
+                                          "note": "the same FLOPs / (unit time - the HBM-bound Winograd transform and finishing "
+                                                  "launches inside the units, timed in an untimed pass): the MFMA kernels alone"}
+            return o
 
-        def family(fam, kernel, ms_, flop_, n_, note):
-            tf = flop_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
-            return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "avg_launch_ms": round(ms_ / max(n_, 1), 4), "launches_per_step": n_,
-                    "ms_per_step": round(ms_, 3), "flop_per_step": flop_, "executed": executed(fam, ms_), "note": note}
+        def hbm_family(fam, ms_, bytes_, n_):
+            """HBM roofline object of the Winograd transform / finishing passes of one conv family."""
+            gbs = bytes_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+            return {"family": fam, "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": round(ms_, 3),
+                    "bytes_per_step": bytes_, "launches_per_step": n_}
+
+        wk = {'fwd': 9, 'dgrad': 10, 'wgrad': 11}
+        wino_fwd_ms = bms[9] / nb if nb else 0.0
+        wino_traffic, wino_traffic_src = wino_traffic_per_step()
+        hb = [hbm_family('fwd', bms[9] / nb, bwork[9] / nb, bcnt[9] / nb), hbm_family('dgrad', *ex[10]),
+              hbm_family('wgrad', *ex[11])]
+        hb_ms = sum(h["ms_per_step"] for h in hb)
+        hb_bytes = sum(h["bytes_per_step"] for h in hb)
+        step_exec = exe['fwd'] + exe['dgrad'] + exe['wgrad'] + 4 * 2.0 * B * H * W * 32 * 27
         res = {
             "metric": "images/sec (fwd+bwd) yolo-pose 416x416 bs=64/GPU",
             "value": round(images_per_s, 2),
@@ -551,36 +656,48 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
             # headline fraction of the step: ALL conv FLOPs of fwd+bwd (87.673 GFLOP per image) over the whole step's
             # wall time - BatchNorm / activation / loss / optimizer time included in the denominator
-            "step_conv_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma",
-                         "kernel": "conv_igemm_dma_kernel<BM, BN, 0, NSLOT, WM, WN>(ConvArgs): the forward launches of "
-                                   "layers 2-30 (Winograd-plan layers: + wino_input_kernel, reduce_kernel<true>; the first "
-                                   "block's two passes are first_block_kernel<0|1>, reported under "
-                                   "kernel_ms_per_step.first_block_fwd, not here)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
-                         "launches_per_step": ig_n / ig_steps,
-                         "flop_per_launch_avg": ig_flop / max(ig_n, 1),
-                         "executed": executed('fwd', ig_ms / max(ig_steps, 1)),
-                         "note": "HIP events around exactly these launches inside the timed region (they run alone on the GPU); "
-                                 "a Winograd-plan layer's three launches (input transform, batched GEMM, finishing pass) are "
-                                 "one timed unit; achieved = algorithmic FLOPs / time (see `executed` for pipe utilisation)"},
-            "roofline_dgrad": family("dgrad", "conv_igemm_dma_kernel<BM, BN, 1, NSLOT, WM, WN>(ConvArgs) (+ conv_igemm_kernel<64, 128, "
-                                     "2, 2, 4, 0, 1> for the 20-channel head)", ex[1][0], ex[1][1], ex[1][2],
+            "step_conv_effective_flop_frac_of_peak": round(images_per_s / world * 87.673e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            # ... and the FLOPs the MFMA pipe really issued in a step (Winograd layers counted as their GEMMs; the first
+            # block's four recomputing passes included) over the same wall time: whole-step pipe utilisation
+            "step_mfma_executed_frac_of_peak": round(step_exec / (dt / args.steps) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "roofline": dict(family("fwd", IGEMM % (0, 0, 0, 0, 0) + "; the forward launch units of layers 2-30 (the first block's "
+                                    "two passes are first_block_kernel<0|1>: kernel_ms_per_step.first_block_fwd)",
+                                    ig_ms / max(ig_steps, 1), ig_n / max(ig_steps, 1),
+                                    "HIP events around exactly these launch units INSIDE the timed region (they run alone on "
+                                    "the GPU); achieved / frac = EXECUTED MFMA FLOPs / that time", wino_ms=wino_fwd_ms),
+                             traffic=traffic, traffic_source=traffic_src),
+            "roofline_dgrad": family("dgrad", IGEMM % (1, 1, 1, 1, 1) + " (+ conv_igemm_kernel<64, 128, 2, 2, 4, 0, 1> for the "
+                                     "20-channel head)", ex[1][0], ex[1][2],
                                      "kernel-exclusive: untimed pass with the filter gradients on the same stream "
-                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues"),
-            "roofline_wgrad": family("wgrad", "conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs)", ex[2][0], ex[2][1],
-                                     ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same stream "
-                                     "(Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
-                                     "(kernel_ms_per_step.first_block_bwd)"),
-            "roofline_bwd": {"bound": "mfma", "kernel": "in the real step: conv dgrad launches (main stream) overlapped with "
-                                                        "conv_wgrad_dma_kernel launches (second stream)",
-                             "achieved": round(bwd_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(bwd_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                             "note": "algorithmic dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times); "
+                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues", wino_ms=ex[10][0]),
+            "roofline_wgrad": family("wgrad", "conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs): <256, 128, 3, false, "
+                                     "false>, <128, 128, 3, ...>, <128, 64, 4, ...>, <64, 128, 4, ...>, <64, 64, 4, true, false>",
+                                     ex[2][0], ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same "
+                                     "stream (Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
+                                     "(kernel_ms_per_step.first_block_bwd)", wino_ms=ex[11][0]),
+            "roofline_bwd": {"bound": "mfma", "kernel": "in the real step: conv dgrad launch units (main stream) overlapped with "
+                                                        "conv_wgrad_dma_kernel launch units (second stream)",
+                             "achieved": round((exe['dgrad'] + exe['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 if bwd_ms > 0 else 0.0, 2),
+                             "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round((exe['dgrad'] + exe['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                                           if bwd_ms > 0 else 0.0, 4),
+                             "effective": {"tflops": round(bwd_tf, 2), "frac_of_peak": round(bwd_tf / PEAK_FP32_MFMA_TFLOPS, 4)},
+                             "note": "EXECUTED dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times); "
                                      "from a separate untimed pass with every launch timed, as kernel_ms_per_step"},
+            # the HBM-bound passes around the Winograd GEMMs: input / output-gradient transforms, finishing passes (inverse
+            # transform + statistics / affine / fused BatchNorm-backward sums), filter-gradient finishing
+            "roofline_wino_transforms": {
+                "bound": "hbm",
+                "kernel": "wino_input_kernel<2, 4>|<4, 2>, wino_output_kernel<2>|<4>, wino_outgrad_kernel<2, 4>|<4, 2>, "
+                          "wino_wgrad_finish_kernel<2>|<4> (conv_wino.hip)",
+                "achieved": round(hb_bytes / (hb_ms * 1e-3) / 1e9 if hb_ms > 0 else 0.0, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(hb_bytes / (hb_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if hb_ms > 0 else 0.0, 4),
+                "ms_per_step": round(hb_ms, 3), "bytes_per_step": hb_bytes, "by_family": hb,
+                "traffic": wino_traffic, "traffic_source": wino_traffic_src,
+                "note": "achieved = ALGORITHMIC bytes of these passes (each operand read once, each result written once) / their "
+                        "HIP-event time: forward passes from the untimed all-timers pass (they run alone), backward ones "
+                        "kernel-exclusive (Plan.serial_backward); traffic = fabric bytes per step of the same kernels from the "
+                        "committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), null while the kernels differ from the profiled ones"},
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()},
             "final_loss": final_loss,
             "verified": verified,

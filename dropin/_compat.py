@@ -18,7 +18,12 @@ def _array_04(self, dtype=None, copy=None):
     if moved and copy is False:
         raise ValueError("a %s tensor cannot be viewed as a numpy array without a copy" % self.device)
     t = self.detach().cpu() if moved else self
-    return _orig_array(t) if dtype is None else _orig_array(t, dtype)
+    a = _orig_array(t) if dtype is None else _orig_array(t, dtype)
+    # copy=True (what NumPy 2 passes for np.array(t)) asks THIS method for a fresh array and does not copy on top of it: a
+    # CPU tensor that was not moved would otherwise come back as torch's zero-copy view and np.array(t) would alias t
+    if copy and not moved:
+        a = a.copy()
+    return a
 
 
 # SSP_DROPIN_ARRAY_COMPAT=0 leaves torch.Tensor.__array__ alone (the reference's drivers then need torch 0.4 semantics from

@@ -44,11 +44,16 @@ int ssp_set_option(const char* name, int value);
  * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
  * models) may run different plans concurrently.  The same code must be passed to the two queries.
  *   9000000 + tile_rows*100 + 10 + ring_slots (3|4|8) = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout > 64
- *   and % 4 == 0; conv_wino.hip): same result to ~1e-6 of its range with 16/36 of the multiplies.  `wt` must then be the
- *   TRANSFORMED filter from ssp_wino_filter_transform (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the workspace
- *   (ssp_conv_workspace_floats: 16 * tiles * (Cin + Cout) floats) is mandatory; a Winograd code on a shape it does not
- *   fit is an error, not a fallback (the filter operand differs).  Valid for ssp_conv_fwd, ssp_conv_fwd_affine,
- *   ssp_conv_dgrad and ssp_conv_dgrad_bnbwd. */
+ *   and % 4 == 0; conv_wino.hip): same result to ~1e-6 of its range with 16/36 of the multiplies;
+ *   8000000 + the same = Winograd F(4x4, 3x3) (points 0, 1, -1, 1/2, -2): 36/144 of the multiplies, result within ~5e-6 of its
+ *   range (about twice the direct fp32 kernel's own rounding error).  `wt` must then be the TRANSFORMED filter from
+ *   ssp_wino_filter_transform_t with the plan's tile size (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the
+ *   workspace (ssp_conv_workspace_floats: (tile+2)^2 * tiles * (Cin + Cout) floats, tiles = B * ceil(H/tile) * ceil(W/tile))
+ *   is mandatory; a Winograd code on a shape it does not fit is an error, not a fallback (the filter operand differs).
+ *   Valid for ssp_conv_fwd, ssp_conv_fwd_affine, ssp_conv_dgrad and ssp_conv_dgrad_bnbwd.
+ * stats of a Winograd plan are in the COUNTED format: ssp_conv_stats_tile_m returns 0, the buffer holds
+ *   [ssp_conv_stats_tiles(...)][Cout][2] (mean, M2) pairs followed by [ssp_conv_stats_tiles(...)] pixel counts
+ *   (ssp_conv_stats_floats floats in all) and ssp_bn_fwd_finalize takes tile_m = 0. */
 int ssp_conv_fwd(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H, int W,
                  int Cin, int Cout, int ldin, int ldout, int R, int accumulate, int plan, float* workspace,
                  int64_t workspace_floats, void* stream);
@@ -59,9 +64,17 @@ int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const floa
                         float slope, int B, int H, int W, int Cin, int Cout, int ldin, int ldout, int R, int plan,
                         float* workspace, int64_t workspace_floats, void* stream);
 int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int plan);
-/* U[xi][row][k] = (G g G^T)[xi], xi = 0..15, of the 3x3 filters g[tap] = w9[row][tap][k] (rows x 9 x K floats, K % 4 == 0):
- * the filter operand of a Winograd plan.  rows = Cout, K = Cin for the forward layout; rows = Cin_dx, K = Cout_dy for the
- * data-gradient layout.  U: 16 * rows * K floats. */
+/* number of statistics tiles of the launch (= rows of its `stats` / of ssp_conv_dgrad_bnbwd's `partial`), and the size of
+ * its `stats` buffer in floats */
+int ssp_conv_stats_tiles(int B, int H, int W, int Cin, int Cout, int R, int plan);
+int64_t ssp_conv_stats_floats(int B, int H, int W, int Cin, int Cout, int R, int plan);
+/* tile size of a plan code: 2 or 4 for a Winograd plan, 0 otherwise */
+int ssp_conv_plan_wino_tile(int plan);
+/* U[xi][row][k] = (G g G^T)[xi], xi = 0..(tile+2)^2-1, of the 3x3 filters g[tap] = w9[row][tap][k] (rows x 9 x K floats,
+ * K % 4 == 0): the filter operand of a Winograd plan of that tile size (2 or 4).  rows = Cout, K = Cin for the forward
+ * layout; rows = Cin_dx, K = Cout_dy for the data-gradient layout.  U: (tile+2)^2 * rows * K floats.
+ * ssp_wino_filter_transform = tile 2. */
+int ssp_wino_filter_transform_t(const float* w9, float* U, int rows, int K, int tile, void* stream);
 int ssp_wino_filter_transform(const float* w9, float* U, int rows, int K, void* stream);
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan);
 
@@ -75,9 +88,9 @@ int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, in
  * activation gradient it writes (darknet.py:157,162 under autograd): dx is g = dL/d leaky(BN(raw)); with that block's
  * raw conv output and forward BN vectors the finishing pass of the launch leaves
  *   partial[tile][c] = (sum over the tile's pixels of dy, of dy * xhat),  dy = g * leaky'(scale*raw + shift),
- *   xhat = (raw - mean) * invstd;   tile = pixel / ssp_conv_stats_tile_m(B,H,W,Cout_dy,Cin_dx,R,plan),
+ *   xhat = (raw - mean) * invstd;   tile = pixel / ssp_conv_stats_tile_m(B,H,W,Cout_dy,Cin_dx,R,plan) (Winograd plans: groups of 16 tiles),
  * i.e. what ssp_bn_act_bwd's reduce pass would re-read g and raw for; ssp_bn_act_bwd_partials finishes the block.
- * partial: partial_rows * Cin_dx * 2 floats.  A launch with ntile = ceil(B*H*W / tile_m) <= partial_rows tiles stores row
+ * partial: partial_rows * Cin_dx * 2 floats.  A launch with ntile = ssp_conv_stats_tiles(...) <= partial_rows tiles stores row
  * `tile` plainly (deterministic); a launch with more tiles folds tile t into row t % partial_rows with fp32 atomic adds,
  * and the buffer must then be ZERO on entry (ssp_bn_act_bwd_partials with zero_after = 1 leaves it so).  Cin_dx % 4 == 0. */
 int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx,
@@ -89,17 +102,24 @@ int ssp_conv_dgrad_bnbwd(const float* dy, const float* wt, float* dx, int B, int
  * zeroed by the caller (split reduction uses fp32 atomics). */
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                    int ldx, int R, void* stream);
-/* The same filter gradient of a 3x3 layer (Cin, Cout >= 64 and % 16 == 0) evaluated in the Winograd F(2x2, 3x3) domain
- * (csrc/conv_wino.hip): dw += the direct result to ~1e-6 of its range with 16/36 of the multiplies.  dw must be 16-byte
+/* The same filter gradient of a 3x3 layer (Cin, Cout >= 64 and % 16 == 0) evaluated in the Winograd F(tile x tile, 3x3)
+ * domain, tile = 2 or 4 (csrc/conv_wino.hip): dw += the direct result to ~1e-6 (tile 2) / ~4e-6 (tile 4: the direct
+ * kernel's own rounding level) of its range with 16/36 / 36/144 of the multiplies.  dw must be 16-byte
  * aligned, [Cout][3][3][Cin] floats (the ssp_repack_fwd layout), written by this launch alone while it runs;
- * workspace: ssp_conv_wgrad_wino_workspace_floats(...) floats.  x == NULL: the transformed input V is already at the head
- * of the workspace - left there by this layer's ssp_conv_fwd with a Winograd plan and the SAME workspace buffer (both
- * layouts start with V [16][tiles][Cin]) - so the layer input is transformed once per training step, not twice. */
+ * workspace: ssp_conv_wgrad_wino_workspace_floats_t(...) floats.  x == NULL: the transformed input V is already at the head
+ * of the workspace - left there by this layer's ssp_conv_fwd with a Winograd plan of the SAME tile size and the SAME
+ * workspace buffer (both layouts start with V [(tile+2)^2][tiles][Cin]) - so the layer input is transformed once per
+ * training step, not twice.  The un-suffixed names = tile 2. */
+int64_t ssp_conv_wgrad_wino_workspace_floats_t(int B, int H, int W, int Cin, int Cout, int tile);
+int ssp_conv_wgrad_wino_t(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                          int ldx, int tile, float* workspace, int64_t workspace_floats, void* stream);
 int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout);
 int ssp_conv_wgrad_wino(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                         int ldx, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- BatchNorm2d(eps) + LeakyReLU(slope) (+ 2x2/2 max-pool): darknet.py:157,162,172 ------------------------- */
+/* stats: `ntile` per-tile (mean, M2) pairs per channel from a conv launch; tile_m = its ssp_conv_stats_tile_m (rows per
+ * tile; the last tile holds M - (ntile-1)*tile_m), or 0 = counted format (the tiles' pixel counts follow the pairs) */
 int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                         float* mean, float* invstd, float* scale, float* shift, void* stream);

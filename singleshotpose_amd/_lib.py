@@ -30,13 +30,19 @@ _SIGS = {
     "ssp_conv_fwd_affine": [P, P, P, P, P, F, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_stats_tile_m": [I, I, I, I, I, I, I],
     "ssp_conv_workspace_floats": [I, I, I, I, I, I, I],
+    "ssp_conv_stats_tiles": [I, I, I, I, I, I, I],
+    "ssp_conv_stats_floats": [I, I, I, I, I, I, I],
+    "ssp_conv_plan_wino_tile": [I],
     "ssp_wino_filter_transform": [P, P, I, I, P],
+    "ssp_wino_filter_transform_t": [P, P, I, I, I, P],
     "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_dgrad_bnbwd": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, I, P, P, P, P, F, P, I, P],
     "ssp_bn_act_bwd_partials": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, I, P, I, I, P, P, P, P, P],
     "ssp_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, P],
     "ssp_conv_wgrad_wino": [P, P, P, I, I, I, I, I, I, I, P, L, P],
     "ssp_conv_wgrad_wino_workspace_floats": [I, I, I, I, I],
+    "ssp_conv_wgrad_wino_t": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],
+    "ssp_conv_wgrad_wino_workspace_floats_t": [I, I, I, I, I, I],
     "ssp_bn_fwd_finalize": [P, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P],
     "ssp_bn_eval_prepare": [I, P, P, P, P, F, P, P, P, P, P],
     "ssp_bn_act_fwd": [P, I, P, I, P, P, I, I, I, I, I, F, P],
@@ -76,10 +82,11 @@ _SIGS = {
     "ssp_prof_collect": [P, P, P],
 }
 
-_RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats')
+_RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats_t',
+          'ssp_conv_stats_floats')
 
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
-              "first_block_bwd")
+              "first_block_bwd", "wino_fwd", "wino_dgrad", "wino_wgrad")
 
 
 def csrc_digest():

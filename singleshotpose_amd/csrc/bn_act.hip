@@ -35,10 +35,12 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const float* __res
                                                               float* invstd_out, float* scale, float* shift) {
   const int c = blockIdx.x, tid = threadIdx.x;
   double n = 0.0, mean = 0.0, m2 = 0.0;
+  // BM == 0: counted format (Winograd finishing pass, conv_wino.hip) - the tiles' pixel counts follow the (mean, M2) pairs
+  const float* counts = stats + (int64_t)ntile * C * 2;
   for (int t = tid; t < ntile; t += 256) {
-    int cnt = min(BM, M - t * BM);
+    const double cnt = BM > 0 ? (double)min(BM, M - t * BM) : (double)counts[t];
     const float* s = stats + ((int64_t)t * C + c) * 2;
-    chan_combine_d(n, mean, m2, (double)cnt, (double)s[0], (double)s[1]);
+    chan_combine_d(n, mean, m2, cnt, (double)s[0], (double)s[1]);
   }
   __shared__ double sn[256], smean[256], sm2[256];
   sn[tid] = n; smean[tid] = mean; sm2[tid] = m2;

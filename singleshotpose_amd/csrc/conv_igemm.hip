@@ -19,6 +19,7 @@
 // agree, so lane (i,h) reads VEC consecutive floats at column h*VEC of its LDS row with one
 // ds_read_b128/b64 and feeds them to VEC successive MFMAs.
 #include "conv_igemm_common.h"
+#include "conv_wino.h"
 
 // ABL: 0 = product kernel; ablation bits for tools/conv_bench.py only (results are garbage): 1 no global loads in
 // the K loop, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 no LDS stores
@@ -287,18 +288,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_igemm_kernel(ConvArgs p) 
 // (mean, M2) statistics in the same format the conv epilogue emits (tile_m rows per tile).  HBM-bound: reads
 // ksplit*M*Cout floats once, writes M*Cout.  Grid = (row tiles, 64-channel slabs); thread = one float4 of channels
 // (16 per slab) x one of 16 row lanes; Welford per thread, Chan-combine of the 16 row lanes through LDS.
-// WINO (conv_wino.hip): the rows come out of the inverse Winograd transform instead - `ws` holds the 16 planes
-// M_xi [T][Cout] of the batched GEMM, output pixel (b, y, x) belongs to tile t = (b, y/2, x/2) and is the signed sum of 9
-// of its 16 values (A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]: rows {0,1,2} for an even y, {1,2,3} with signs (+,-,-) for
-// an odd one; the same over the columns).  Everything after the gather is shared.
-struct WinoOut {
-  int H, W, th, tw;
-  int64_t T;
-  SspFastDiv div_w, div_h;
-};
-
-template <bool WINO>
-__global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
+// (Winograd plans have their own finishing pass: wino_output_kernel, conv_wino.hip.)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* out, int ldout,
                                                      const float* __restrict__ bias, float* stats, int M,
                                                      int Cout, int tile_m, int accumulate,
                                                      const float* __restrict__ escale, float act_slope,
@@ -307,7 +298,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ w
                                                      const float* __restrict__ bn_shift,
                                                      const float* __restrict__ bn_mean,
                                                      const float* __restrict__ bn_invstd, float bn_slope,
-                                                     float* bn_partial, int bn_nslot, int ntile_all, WinoOut wo) {
+                                                     float* bn_partial, int bn_nslot, int ntile_all) {
   // rows [row0, M) (row0 a multiple of tile_m); workspace row m sits at m - row0, split stride (M - row0) rows
   const int tid = threadIdx.x, gl = tid & 15, pp = tid >> 4;
   const int c = blockIdx.y * 64 + gl * 4;
@@ -331,27 +322,6 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ w
   if (cok) {
     for (int m = m0 + pp; m < m1; m += 16) {
       f32x4 v;
-      if constexpr (WINO) {
-        const unsigned q = ssp_div((unsigned)m, wo.div_w);                 // b * H + y
-        const int x = m - (int)q * wo.W;
-        const unsigned b = ssp_div(q, wo.div_h);
-        const int y = (int)(q - b * (unsigned)wo.H);
-        const int64_t t = ((int64_t)b * wo.th + (y >> 1)) * wo.tw + (x >> 1);
-        const int i0 = y & 1, j0 = x & 1;
-        const float* src = ws + t * Cout + c;
-        const int64_t plane = wo.T * Cout;
-        f32x4 u[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            u[i][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)((i0 + i) * 4 + j0 + j) * plane);
-        // even position: + + +, odd position: + - - (over the three planes it reads)
-        f32x4 rr[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rr[i] = j0 ? (u[i][0] - u[i][1] - u[i][2]) : (u[i][0] + u[i][1] + u[i][2]);
-        v = i0 ? (rr[0] - rr[1] - rr[2]) : (rr[0] + rr[1] + rr[2]);
-      } else {
       v = *reinterpret_cast<const f32x4*>(ws + (int64_t)m * Cout + c);
       int sp = 1;
       for (; sp + 3 < ksplit; sp += 4) {       // four partial loads in flight; summation order unchanged (sp ascending)
@@ -364,7 +334,6 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ w
       for (; sp < ksplit; ++sp) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(ws + ((int64_t)sp * ws_rows + m) * Cout + c);
         v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
-      }
       }
       cnt += 1.f;
       const float inv = 1.f / cnt;
@@ -524,7 +493,7 @@ static IgemmPlan select_plan(int M, int Cin, int Cout, int R, int plan_code) {
   return pl;
 }
 int ssp_conv_tile_m(int M, int Cin, int Cout, int R, int plan) {
-  if (plan >= 9000000 && plan < 10000000) return 64;      // Winograd plans: SSP_WINO_TILE_M rows per finishing workgroup
+  if (ssp_wino_plan_tile(plan)) return 0;      // Winograd plans: statistics per group of SSP_WINO_TG tiles, counted format
   return select_plan(M, Cin, Cout, R, plan).bm;
 }
 int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan) {
@@ -533,51 +502,48 @@ int64_t ssp_conv_ws_floats(int M, int Cin, int Cout, int R, int plan) {
   return deepest > 1 ? (int64_t)deepest * M * Cout : 0;
 }
 
-// ---- Winograd F(2x2, 3x3) path (conv_wino.hip): plan codes 9000000 + bm * 100 + 10 + slots ----
-// `wt` is then the TRANSFORMED filter U [16][Cout][Cin] (ssp_wino_filter_transform), the workspace holds the transformed
-// input V [16][T][Cin] followed by the GEMM output M [16][T][Cout] (ssp_conv_workspace_floats says how much), and the
-// launch is three kernels: input transform, ONE batched launch of the LDS-direct GEMM kernel (gridDim.y = 16), and the
-// finishing pass reduce_kernel<true> (inverse transform + everything the split-K finish does).
-int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int W, int C, hipStream_t stream);   // conv_wino.hip
-#define SSP_WINO_PLAN 9000000
-static inline bool is_wino_plan(int plan) { return plan >= SSP_WINO_PLAN && plan < SSP_WINO_PLAN + 1000000; }
-int64_t ssp_wino_tiles(int B, int H, int W) { return (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2); }
-int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout) { return 16 * ssp_wino_tiles(B, H, W) * ((int64_t)Cin + Cout); }
-#define SSP_WINO_TILE_M 64      // rows per finishing workgroup = rows per BatchNorm-statistics tile of a Winograd launch
+// ---- Winograd path (conv_wino.hip): plan codes 9000000 (F(2x2,3x3)) / 8000000 (F(4x4,3x3)) + bm * 100 + 10 + slots ----
+// `wt` is then the TRANSFORMED filter U [P][Cout][Cin] (ssp_wino_filter_transform_t, P = 16 / 36), the workspace holds the
+// transformed input V [P][T][Cin] followed by the GEMM output M [P][T][Cout] (ssp_conv_workspace_floats says how much),
+// and the launch is three kernels: input transform, ONE batched launch of the LDS-direct GEMM kernel (gridDim.y = P), and
+// the finishing pass wino_output_kernel (inverse transform + everything the split-K finish does).
+int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile) {
+  return ssp_wino_planes(tile) * ssp_wino_tiles(B, H, W, tile) * ((int64_t)Cin + Cout);
+}
 
 static int wino_launch(ConvArgs& a, int B, int H, int W, float* ws, int64_t ws_floats, int plan, int prof_kind,
                        hipStream_t stream) {
-  const int bm = (plan / 100) % 1000, slots = plan % 10;
+  const int bm = (plan / 100) % 1000, slots = plan % 10, tile = ssp_wino_plan_tile(plan), P = ssp_wino_planes(tile);
   SSP_CHECK_ARG(a.R == 3 && a.Cin % 16 == 0 && a.Cout > 64 && a.Cout % 4 == 0 && a.ldout % 4 == 0 && (((uintptr_t)a.out) & 15) == 0,
                 "conv (Winograd plan): needs a 3x3 filter, Cin %% 16 == 0, Cout > 64 and %% 4 == 0, an aligned output");
-  SSP_CHECK_ARG((bm == 64 || bm == 128) && (slots == 3 || slots == 4 || slots == 8) && (plan / 10) % 10 == 1, "conv: bad Winograd plan code %d", plan);
-  const int64_t T = ssp_wino_tiles(B, H, W);
-  SSP_CHECK_ARG(T < (1ll << 31) && 16 * T * (int64_t)a.Cin < (1ll << 40), "conv (Winograd plan): too many tiles");
-  SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_wino_ws_floats(B, H, W, a.Cin, a.Cout) && (((uintptr_t)ws) & 15) == 0,
+  SSP_CHECK_ARG((bm == 64 || bm == 128) && (slots == 3 || slots == 4 || slots == 8) && (plan / 10) % 10 == 1 &&
+                    (plan / 100000) % 10 == 0, "conv: bad Winograd plan code %d", plan);
+  const int64_t T = ssp_wino_tiles(B, H, W, tile);
+  SSP_CHECK_ARG(T < (1ll << 31) && P * T * (int64_t)a.Cin < (1ll << 40), "conv (Winograd plan): too many tiles");
+  SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_wino_ws_floats(B, H, W, a.Cin, a.Cout, tile) && (((uintptr_t)ws) & 15) == 0,
                 "conv (Winograd plan): needs a workspace of %lld floats (ssp_conv_workspace_floats)",
-                (long long)ssp_wino_ws_floats(B, H, W, a.Cin, a.Cout));
+                (long long)ssp_wino_ws_floats(B, H, W, a.Cin, a.Cout, tile));
   SSP_CHECK_ARG((int64_t)(128 + 2) * a.Cin * 4 + (int64_t)a.Cin * 4 < (1ll << 31), "conv (Winograd plan): Cin too large");
+  if (a.bn_partial != nullptr) SSP_CHECK_ARG(a.bn_ld % 4 == 0, "conv (Winograd plan): bn_ld must be a multiple of 4");
   SspProfScope prof(prof_kind, stream, 2.0 * (double)a.M * a.Cout * 9.0 * a.Cin);      // algorithmic (direct) FLOPs
   float* V = ws;
-  float* Mw = ws + 16 * T * a.Cin;
-  if (int rc = ssp_wino_input_launch(a.in, a.ldin, V, B, H, W, a.Cin, stream)) return rc;
+  float* Mw = ws + P * T * a.Cin;
+  const int wkind = prof_kind == SSP_PROF_CONV_DGRAD ? SSP_PROF_WINO_DGRAD : SSP_PROF_WINO_FWD;
+  if (int rc = ssp_wino_input_launch(a.in, a.ldin, V, B, H, W, a.Cin, tile, wkind, stream)) return rc;
   ConvArgs g = a;
   g.in = V; g.wt = a.wt; g.out = Mw; g.bias = nullptr; g.escale = nullptr; g.act_slope = 1.f; g.stats = nullptr;
   g.H = 1; g.W = (int)T; g.ldin = a.Cin; g.ldout = a.Cout; g.R = 1; g.M = (int)T; g.accumulate = 0;
   g.divW = ssp_fastdiv((unsigned)T); g.divH = ssp_fastdiv(1u);
   g.ws = nullptr; g.ksplit = 1; g.probe = 0;
   g.bn_partial = nullptr; g.bn_raw = nullptr;
-  g.batch = 16; g.batch_in = T * a.Cin; g.batch_wt = (int64_t)a.Cout * a.Cin; g.batch_out = T * a.Cout;
+  g.batch = P; g.batch_in = T * a.Cin; g.batch_wt = (int64_t)a.Cout * a.Cin; g.batch_out = T * a.Cout;
   if (int rc = ssp_conv_igemm_dma_launch(g, bm, slots, 0, prof_kind == SSP_PROF_CONV_DGRAD, stream)) return rc;
-  WinoOut wo;
-  wo.H = H; wo.W = W; wo.th = (H + 1) / 2; wo.tw = (W + 1) / 2; wo.T = T;
-  wo.div_w = ssp_fastdiv((unsigned)W); wo.div_h = ssp_fastdiv((unsigned)H);
-  hipLaunchKernelGGL(reduce_kernel<true>, dim3(ssp_cdiv(a.M, SSP_WINO_TILE_M), ssp_cdiv(a.Cout, 64)), dim3(256), 0, stream, Mw, 1,
-                     a.out, a.ldout, a.bias, a.stats, a.M, a.Cout, SSP_WINO_TILE_M, a.accumulate, a.escale, a.act_slope, 0, a.bn_raw,
-                     a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot,
-                     ssp_cdiv(a.M, SSP_WINO_TILE_M), wo);
-  SSP_CHECK_LAUNCH("wino_output");
-  return SSP_OK;
+  WinoOutArgs o;
+  o.Mw = Mw; o.out = a.out; o.bias = a.bias; o.escale = a.escale; o.act_slope = a.act_slope; o.stats = a.stats;
+  o.Cout = a.Cout; o.ldout = a.ldout; o.accumulate = a.accumulate;
+  o.bn_raw = a.bn_raw; o.bn_scale = a.bn_scale; o.bn_shift = a.bn_shift; o.bn_mean = a.bn_mean; o.bn_invstd = a.bn_invstd;
+  o.bn_partial = a.bn_partial; o.bn_nslot = a.bn_nslot; o.bn_ld = a.bn_ld; o.bn_slope = a.bn_slope;
+  return ssp_wino_output_launch(o, B, H, W, tile, wkind, stream);
 }
 
 int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const float* bias, float* stats, int B, int H,
@@ -614,7 +580,7 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     SSP_CHECK_ARG(bnb->nslot >= 1, "conv: the BatchNorm-backward partial buffer needs at least one row");
     a.bn_nslot = bnb->nslot;
   }
-  if (is_wino_plan(plan)) return wino_launch(a, B, H, W, ws, ws_floats, plan, prof_kind, stream);
+  if (ssp_wino_plan_tile(plan)) return wino_launch(a, B, H, W, ws, ws_floats, plan, prof_kind, stream);
   IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
   if (Cout <= 64 && pl.ksplit > 1 &&
       (ws == nullptr || ws_floats < (int64_t)pl.ksplit * a.M * Cout || ldout % 4 != 0 || (((uintptr_t)out) & 15) != 0))
@@ -684,15 +650,15 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
   // to use 16-row blocks (one row per thread: 4-8x the workgroups on the small grids of batch-1 inference)
   const int rt = (stats == nullptr && a.bn_partial == nullptr && a.M <= 16384) ? 16 : pl.bm;
   if (pl.ksplit > 1) {
-    hipLaunchKernelGGL(reduce_kernel<false>, dim3(ssp_cdiv(a.M, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws, pl.ksplit, out, ldout,
                        bias, stats, a.M, Cout, rt, accumulate, escale, act_slope, 0, a.bn_raw, a.bn_ld, a.bn_scale,
-                       a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot, ssp_cdiv(a.M, pl.bm), WinoOut{});
+                       a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot, ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce");
   } else if (a.tail_ks > 1) {     // hybrid launch: only the tail rows were left as partials
-    hipLaunchKernelGGL(reduce_kernel<false>, dim3(ssp_cdiv(a.M - a.ws_row0, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ssp_cdiv(a.M - a.ws_row0, rt), ssp_cdiv(Cout, 64)), dim3(256), 0, stream, ws,
                        a.tail_ks, out, ldout, bias, stats, a.M, Cout, rt, accumulate, escale, act_slope, a.ws_row0,
                        a.bn_raw, a.bn_ld, a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd, a.bn_slope, a.bn_partial, a.bn_nslot,
-                       ssp_cdiv(a.M, pl.bm), WinoOut{});
+                       ssp_cdiv(a.M, pl.bm));
     SSP_CHECK_LAUNCH("splitk_reduce(tail)");
   }
   return SSP_OK;

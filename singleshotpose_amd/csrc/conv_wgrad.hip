@@ -13,7 +13,7 @@
 // The pixel reduction is split across workgroups (grid.x = tiles * taps * nsplit) and - for
 // thin layers - across the waves of a workgroup (WK); partial tiles are summed into dW with
 // hardware fp32 atomics, so the caller zeroes dW first.
-#include "ssp_common.h"
+#include "conv_wino.h"
 
 struct WgradArgs {
   const float* dy;
@@ -352,10 +352,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
 
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                            int ldx, int R, hipStream_t stream, int batch = 0, int64_t batch_dy = 0, int64_t batch_x = 0,
-                           int64_t batch_dw = 0);   // conv_wgrad_dma.hip
-int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int W, int C, hipStream_t stream);      // conv_wino.hip
-int ssp_wino_outgrad_launch(const float* dy, int lddy, float* dM, int B, int H, int W, int C, hipStream_t stream);
-int ssp_wino_wgrad_finish_launch(const float* dU, float* dw, int rows, int K, hipStream_t stream);
+                           int64_t batch_dw = 0, int overwrite = 0);   // conv_wgrad_dma.hip
 
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout,
                           int lddy, int ldx, int R, hipStream_t stream) {
@@ -398,41 +395,41 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
 
 
 // Filter gradient of a 3x3 layer in the Winograd domain (conv_wino.hip): transform the input (B^T d B) and the output
-// gradient (A dY A^T) into 16 planes each, contract the planes pairwise over the tiles in ONE batched launch of the
-// LDS-direct filter-gradient kernel, map the 16 results back onto the 9 taps (G^T . G) and add them to dw.
-// workspace: V [16][T][Cin] | dM [16][T][Cout] | dU [16][Cout][Cin] (ssp_conv_wgrad_wino_ws_floats); V sits where a
-// Winograd forward launch puts it (workspace head), so a caller that hands both launches the same buffer transforms the
-// layer input once per step.
-int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout) {
-  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  return 16 * (T * ((int64_t)Cin + Cout) + (int64_t)Cin * Cout);
+// gradient (A dY A^T) into P = (tile + 2)^2 planes each, contract the planes pairwise over the tiles in ONE batched launch
+// of the LDS-direct filter-gradient kernel, map the P results back onto the 9 taps (G^T . G) and add them to dw.
+// workspace: V [P][T][Cin] | dM [P][T][Cout] | dU [P][Cout][Cin] (ssp_conv_wgrad_wino_ws_floats); V sits where a
+// Winograd forward launch of the same tile size puts it (workspace head), so a caller that hands both launches the same
+// buffer transforms the layer input once per step.  dU needs no clearing by the caller: an un-split batched launch writes
+// it with plain stores, a split one zeroes it first.
+int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile) {
+  const int64_t T = ssp_wino_tiles(B, H, W, tile);
+  return ssp_wino_planes(tile) * (T * ((int64_t)Cin + Cout) + (int64_t)Cin * Cout);
 }
 int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
-                               int ldx, float* ws, int64_t ws_floats, hipStream_t stream) {
+                               int ldx, int tile, float* ws, int64_t ws_floats, hipStream_t stream) {
+  SSP_CHECK_ARG(tile == 2 || tile == 4, "wgrad (Winograd): tile must be 2 or 4");
   SSP_CHECK_ARG(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 64 && Cout >= 64, "wgrad (Winograd): needs Cin, Cout >= 64 and %% 16 == 0");
   SSP_CHECK_ARG(ldx % 4 == 0 && ldx >= Cin && lddy % 4 == 0 && lddy >= Cout, "wgrad (Winograd): bad leading dimensions");
   SSP_CHECK_ARG((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)ws)) % 16 == 0, "wgrad (Winograd): operands must be 16-byte aligned");
-  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const int64_t T = ssp_wino_tiles(B, H, W, tile);
+  const int P = ssp_wino_planes(tile);
   SSP_CHECK_ARG(T >= 16 && T < (1ll << 31), "wgrad (Winograd): tile count out of range (>= 16 tiles)");
-  SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout),
+  SSP_CHECK_ARG(ws != nullptr && ws_floats >= ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout, tile),
                 "wgrad (Winograd): needs a workspace of %lld floats (ssp_conv_wgrad_wino_workspace_floats)",
-                (long long)ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout));
+                (long long)ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout, tile));
   SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)B * H * W * Cout * 9.0 * Cin);      // algorithmic (direct) FLOPs
   float* V = ws;
-  float* dM = V + 16 * T * Cin;
-  float* dU = dM + 16 * T * Cout;
+  float* dM = V + P * T * Cin;
+  float* dU = dM + P * T * Cout;
   // x == nullptr: the transformed input is already at the head of the workspace - the forward launch of the same layer
-  // (a Winograd plan of ssp_conv_fwd given THIS workspace) left V there, and nothing has written the region since
+  // (a Winograd plan of ssp_conv_fwd with the same tile size, given THIS workspace) left V there, and nothing has written
+  // the region since
   if (x != nullptr)
-    if (int rc = ssp_wino_input_launch(x, ldx, V, B, H, W, Cin, stream)) return rc;
-  if (int rc = ssp_wino_outgrad_launch(dy, lddy, dM, B, H, W, Cout, stream)) return rc;
-  if (hipMemsetAsync(dU, 0, (size_t)16 * Cin * Cout * 4, stream) != hipSuccess) {
-    ssp_set_error("wgrad (Winograd): hipMemsetAsync failed");
-    return SSP_ERR_HIP;
-  }
-  const int r = ssp_conv_wgrad_dma_try(dM, V, dU, 1, 1, (int)T, Cin, Cout, Cout, Cin, 1, stream, 16, T * Cout, T * Cin,
-                                       (int64_t)Cout * Cin);
+    if (int rc = ssp_wino_input_launch(x, ldx, V, B, H, W, Cin, tile, SSP_PROF_WINO_WGRAD, stream)) return rc;
+  if (int rc = ssp_wino_outgrad_launch(dy, lddy, dM, B, H, W, Cout, tile, stream)) return rc;
+  const int r = ssp_conv_wgrad_dma_try(dM, V, dU, 1, 1, (int)T, Cin, Cout, Cout, Cin, 1, stream, P, T * Cout, T * Cin,
+                                       (int64_t)Cout * Cin, 1);
   if (r < 0) return r;
   SSP_CHECK_ARG(r == 1, "wgrad (Winograd): shape declined by the LDS-direct filter-gradient kernel");
-  return ssp_wino_wgrad_finish_launch(dU, dw, Cout, Cin, stream);
+  return ssp_wino_wgrad_finish_launch(dU, dw, Cout, Cin, tile, stream);
 }

@@ -28,6 +28,13 @@ struct WgradArgs {
   // shape; problem b reads dy + b * batch_dy, x + b * batch_x and accumulates into dw + b * batch_dw.  0 / 1: one problem.
   int batch;
   int64_t batch_dy, batch_x, batch_dw;
+  // The caller promises that nothing else accumulates into dw during this launch and does not need the previous contents
+  // (the transform-domain gradient dU of a Winograd filter gradient): a launch that does not split the pixel range then
+  // writes its tiles with plain stores (store = 1, set by the launcher) and a split one zeroes `zero_bytes` bytes at
+  // `zero_ptr` first - instead of a memset in front of every launch.
+  int store;
+  void* zero_ptr;
+  size_t zero_bytes;
 };
 
 #define SSP_OOB 0x80000000u
@@ -348,7 +355,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           asm volatile("" : "+s"(so));          // one live SGPR, one s_add per element (see conv_igemm_common.h)
-          (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rs, voff, so, 0);
+          const float v = acc[i][j][r];
+          if (p.store) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, so, 0);
+          else (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, voff, so, 0);
           so += (((r & 3) == 3) ? 5 : 1) * TM * row4;
         }
       }
@@ -365,7 +374,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * WTM + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
-        if (co < p.Cout && ci < p.Cin && tl < taps) atomicAdd(dw_b + ((int64_t)co * taps + tl) * p.Cin + ci, acc[i][j][r]);
+        if (co < p.Cout && ci < p.Cin && tl < taps) {
+          float* dst = dw_b + ((int64_t)co * taps + tl) * p.Cin + ci;
+          if (p.store) *dst = acc[i][j][r];
+          else atomicAdd(dst, acc[i][j][r]);
+        }
       }
     }
 #endif
@@ -437,6 +450,13 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   nsplit = (a.M + chunk - 1) / chunk;
   a.nsplit = (int)nsplit;
   a.chunk_m = (int)chunk;
+  if (a.zero_ptr != nullptr) {
+    a.store = nsplit == 1 ? 1 : 0;
+    if (!a.store && hipMemsetAsync(a.zero_ptr, 0, a.zero_bytes, stream) != hipSuccess) {
+      ssp_set_error("conv_wgrad_dma: hipMemsetAsync failed");
+      return SSP_ERR_HIP;
+    }
+  }
   int64_t nwg = a.xcd_order ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
   if (order2) {
     a.xcd_order = 2;
@@ -451,7 +471,7 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
 // returns 1 when the shape is handled here (launched), 0 when the caller should use conv_wgrad.hip, < 0 on error
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                            int ldx, int R, hipStream_t stream, int batch, int64_t batch_dy, int64_t batch_x,
-                           int64_t batch_dw) {
+                           int64_t batch_dw, int overwrite) {
   if (Cout < 64 || (Cin < 64 && !(Cin == 32 && R == 3))) return 0;   // Cin 32: two taps fold into one 64-column tile
   if (W < 8) return 0;   // the per-lane pixel walker advances 16 pixels with at most two row wraps
   const int64_t M = (int64_t)B * H * W;
@@ -461,6 +481,13 @@ int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, in
   a.dy = dy; a.x = x; a.dw = dw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy; a.ldx = ldx; a.R = R; a.M = (int)M;
   a.batch = batch; a.batch_dy = batch_dy; a.batch_x = batch_x; a.batch_dw = batch_dw;
+  a.store = 0;
+  a.zero_ptr = nullptr;
+  a.zero_bytes = 0;
+  if (overwrite) {      // dw = result (not +=): the launcher stores when it does not split, zeroes first when it does
+    a.zero_ptr = dw;
+    a.zero_bytes = (size_t)(batch > 1 ? batch : 1) * (size_t)(batch > 1 ? batch_dw : (int64_t)Cout * R * R * Cin) * 4;
+  }
   int rc;
   const int wv = ssp_option(SSP_OPT_WGRAD_VARIANT);
   if (Cin == 32) rc = (Cout >= 128) ? launch_wgrad_dma<128, 64, 4, true>(a, stream) : launch_wgrad_dma<64, 64, 4, true>(a, stream);

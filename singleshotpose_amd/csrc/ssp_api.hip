@@ -5,7 +5,7 @@
 #include <vector>
 
 #include "../../include/ssp_hip.h"
-#include "ssp_common.h"
+#include "conv_wino.h"
 
 // ---- kernels' host launchers (defined next to the kernels) ----
 int ssp_conv_tile_m(int M, int Cin, int Cout, int R, int plan);
@@ -14,13 +14,12 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
                           int W, int Cin, int Cout, int ldin, int ldout, int R, int accumulate, float* ws,
                           int64_t ws_floats, int plan, int prof_kind, hipStream_t stream,
                           const float* escale = nullptr, float act_slope = 1.f, const SspBnBwdFuse* bnb = nullptr);
-int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout);
-int ssp_wino_filter_launch(const float* w, float* U, int rows, int K, hipStream_t stream);
+int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile);
 int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int R, hipStream_t stream);
-int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout);
+int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile);
 int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
-                               int ldx, float* ws, int64_t ws_floats, hipStream_t stream);
+                               int ldx, int tile, float* ws, int64_t ws_floats, hipStream_t stream);
 int ssp_bn_fwd_finalize_launch(const float* stats, int ntile, int BM, int M, int C, const float* gamma,
                                const float* beta, float* rmean, float* rvar, float momentum, float eps, float* mean,
                                float* invstd, float* scale, float* shift, hipStream_t stream);
@@ -165,7 +164,7 @@ SspProfScope::~SspProfScope() {
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err; }
-int ssp_abi_version(void) { return 2; }
+int ssp_abi_version(void) { return 3; }
 int ssp_set_option(const char* name, int value) {
   for (int i = 0; i < SSP_OPT_COUNT; ++i)
     if (name != nullptr && strcmp(name, g_option_names[i]) == 0) {
@@ -191,12 +190,24 @@ int ssp_conv_fwd_affine(const float* in, const float* wt, float* out, const floa
 int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int plan) {
   return ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan);
 }
+int ssp_conv_plan_wino_tile(int plan) { return ssp_wino_plan_tile(plan); }
+int ssp_conv_stats_tiles(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  if (const int tile = ssp_wino_plan_tile(plan)) return (int)ssp_wino_stat_groups(B, H, W, tile);
+  return ssp_cdiv((int64_t)B * H * W, ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan));
+}
+int64_t ssp_conv_stats_floats(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  const int64_t nt = ssp_conv_stats_tiles(B, H, W, Cin, Cout, R, plan);
+  return nt * Cout * 2 + (ssp_wino_plan_tile(plan) ? nt : 0);
+}
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan) {
-  if (plan >= 9000000 && plan < 10000000) return ssp_wino_ws_floats(B, H, W, Cin, Cout);      // Winograd plans: V + M planes
+  if (const int tile = ssp_wino_plan_tile(plan)) return ssp_wino_ws_floats(B, H, W, Cin, Cout, tile);      // V + M planes
   return ssp_conv_ws_floats(B * H * W, Cin, Cout, R, plan);
 }
+int ssp_wino_filter_transform_t(const float* w9, float* U, int rows, int K, int tile, void* stream) {
+  return ssp_wino_filter_launch(w9, U, rows, K, tile, (hipStream_t)stream);
+}
 int ssp_wino_filter_transform(const float* w9, float* U, int rows, int K, void* stream) {
-  return ssp_wino_filter_launch(w9, U, rows, K, (hipStream_t)stream);
+  return ssp_wino_filter_launch(w9, U, rows, K, 2, (hipStream_t)stream);
 }
 
 int ssp_conv_dgrad(const float* dy, const float* wt, float* dx, int B, int H, int W, int Cout_dy, int Cin_dx, int lddy,
@@ -261,12 +272,19 @@ int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int
   return ssp_conv_wgrad_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, R, (hipStream_t)stream);
 }
 
+int64_t ssp_conv_wgrad_wino_workspace_floats_t(int B, int H, int W, int Cin, int Cout, int tile) {
+  return ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout, tile);
+}
+int ssp_conv_wgrad_wino_t(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                          int ldx, int tile, float* workspace, int64_t workspace_floats, void* stream) {
+  return ssp_conv_wgrad_wino_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, tile, workspace, workspace_floats, (hipStream_t)stream);
+}
 int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout) {
-  return ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout);
+  return ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout, 2);
 }
 int ssp_conv_wgrad_wino(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                         int ldx, float* workspace, int64_t workspace_floats, void* stream) {
-  return ssp_conv_wgrad_wino_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, workspace, workspace_floats, (hipStream_t)stream);
+  return ssp_conv_wgrad_wino_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, 2, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 int ssp_bn_fwd_finalize(const float* stats, int ntile, int tile_m, int M, int C, const float* gamma,

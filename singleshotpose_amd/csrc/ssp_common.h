@@ -45,7 +45,12 @@ enum SspProfKind {
   SSP_PROF_OPTIM = 6,      // fused SGD step
   SSP_PROF_FIRST_FWD = 7,  // first block, fused with recompute (conv_first.hip): statistics pass + apply pass
   SSP_PROF_FIRST_BWD = 8,  // first block: BatchNorm-backward reduce pass + filter-gradient pass
-  SSP_PROF_NKINDS = 9
+  // Winograd transform / finishing passes (conv_wino.hip; HBM-bound, work = algorithmic bytes), by the conv family of the
+  // launch they belong to; nested INSIDE that family's scope (its time includes them)
+  SSP_PROF_WINO_FWD = 9,
+  SSP_PROF_WINO_DGRAD = 10,
+  SSP_PROF_WINO_WGRAD = 11,
+  SSP_PROF_NKINDS = 12
 };
 
 struct SspProfScope {

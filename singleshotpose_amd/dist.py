@@ -49,9 +49,11 @@ class GradReducer(object):
         self._lo = self._hi = 0
         self._tail_closed = False
         self.launched = []     # (lo, hi) of every bucket of the last backward (introspection / tests)
+        self.enabled = True    # False: the reducer stands aside (bench.py's untimed local-gradient reference step)
         self.profile = False   # record HIP events per bucket (bench.py's untimed diagnostic steps)
         self._events = []      # (lo, hi, issue event, done event) of the last profiled step
         self._join = None      # (backward-complete event, all-buckets-complete event) of the last profiled step
+        self._probe = None     # profiling only: a stream that waits on each collective alone and records its completion
         if model is not None:
             model._reducer = self
             for plan in getattr(model, '_plans', {}).values():
@@ -59,24 +61,35 @@ class GradReducer(object):
 
     @property
     def active(self):
-        return self.world > 1 or self.force
+        return self.enabled and (self.world > 1 or self.force)
 
     def _launch(self, lo, hi):
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        ev = None
+        ev = done = None
         if self.profile:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()            # on the stream the bucket's last filter gradient was queued on
         work = dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, lo, hi, ev))
+        if self.profile and self._flat.is_cuda:
+            # the collective's OWN completion: a probe stream that waits for this work alone (not the compute stream's
+            # join at the end of backward, which would stamp every bucket with the end of the pass)
+            if self._probe is None:
+                self._probe = torch.cuda.Stream(device=self._flat.device)
+            with torch.cuda.stream(self._probe):
+                work.wait()
+                done = torch.cuda.Event(enable_timing=True)
+                done.record()
+        self._pending.append((work, lo, hi, ev, done))
 
     def begin(self, flat):
         """A backward pass starts writing gradients into `flat` (Plan.backward)."""
         if not self.active:
             return
-        if self._pending:      # a previous backward's buckets were never joined (no all_reduce() call): join them now
+        # a previous backward's buckets were never joined (no all_reduce() call) - launched ones or just an open one (a
+        # model smaller than a bucket, gradient accumulation over two backwards): join them now
+        if self._pending or (self._flat is not None and self._lo is not None and self._hi > self._lo):
             self.all_reduce()
         self._flat, self._lo, self._hi, self._tail_closed = flat, None, None, False
         self.launched = []
@@ -110,14 +123,15 @@ class GradReducer(object):
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record()            # the current stream has joined the backward pass: everything before this is compute
             self._events = []
-        for work, lo, hi, ev in self._pending:
+        t1 = None
+        for work, lo, hi, ev, done in self._pending:
             work.wait()
             if self.profile:
-                done = torch.cuda.Event(enable_timing=True)
-                done.record()
                 self._events.append((lo, hi, ev, done))
         if self.profile:
-            self._join = (t0, self._events[-1][3] if self._events else t0)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()            # the compute stream has every collective behind it
+            self._join = (t0, t1)
         self._pending = []
         self._flat = None
 
@@ -127,11 +141,15 @@ class GradReducer(object):
         earlier buckets included - and the exposed tail: how long the compute stream sat waiting for collectives after
         the backward pass had ended."""
         out = {"backend": dist.get_backend(self.group) if dist.is_initialized() else None, "ranks": self.world,
+               # read back from the process group itself (not from the launcher's environment)
+               "group_ranks": dist.get_world_size(self.group) if dist.is_initialized() else None,
                "bucket_bytes": self.bucket_elems * 4, "tail_bytes": self.tail_elems * 4,
                "buckets_bytes": [(hi - lo) * 4 for lo, hi in self.launched]}
         if self._events and self._join is not None:
             torch.cuda.synchronize()
-            out["bucket_issue_to_done_ms"] = [round(ev.elapsed_time(done), 3) if ev is not None else None
+            # issue = the bucket's last filter gradient queued; done = that collective complete (probe stream): queueing
+            # behind the bucket before it included, the rest of the backward pass not
+            out["bucket_issue_to_done_ms"] = [round(ev.elapsed_time(done), 3) if ev is not None and done is not None else None
                                               for _, _, ev, done in self._events]
             out["exposed_tail_ms"] = round(self._join[0].elapsed_time(self._join[1]), 3)
         return out

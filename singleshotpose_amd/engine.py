@@ -21,6 +21,21 @@ from . import _lib
 from .cfg import layer_shapes, resolve_layers
 
 WINO = 9000000       # plan codes WINO + tile_rows*100 + 10 + ring_slots: Winograd F(2x2, 3x3) evaluation (csrc/conv_wino.hip)
+WINO4 = 8000000      # ... and WINO4 + the same: F(4x4, 3x3)
+
+
+def _tune_tag():
+    """Candidate-set tag, part of every tune-cache key: a cache entry written before a family of candidates existed, or in a
+    process that had it switched off (SSP_WINOGRAD=0, SSP_WINO_TILES, SSP_WINO_MIN_CHANNELS), must not keep that family
+    from ever being timed - and must not hand a Winograd code to a process that switched it off."""
+    if os.environ.get('SSP_WINOGRAD', '1') == '0':
+        return 'r4-direct'
+    return 'r4-w%s-c%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'))
+
+
+def wino_tile(code):
+    """Output-tile edge of a plan code: 2 / 4 for a Winograd plan, 0 for a direct one (ssp_conv_plan_wino_tile)."""
+    return 2 if WINO <= code < WINO + 1000000 else (4 if WINO4 <= code < WINO4 + 1000000 else 0)
 BN_EPS = 1e-4        # darknet.py:157
 BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
 
@@ -31,7 +46,7 @@ _WEIGHTS_EPOCH = [0]
 # autotuned igemm plan per launch shape, shared by every Plan of the process: multi-scale training (dataset.py:66-90
 # draws a new resolution every 10 batches) revisits the same ~20 shapes, each is timed once
 _TUNE_CACHE = {}
-_TUNE_VERIFIED = set()         # launch shapes whose non-default plan passed verify-after-tune in this process
+_TUNE_VERIFIED = {}            # launch shape -> the plan code that passed verify-after-tune in this process
 TUNE_REJECTED = []             # (shape key, plan code) pairs verify-after-tune refused
 _TUNE_CACHE_FILE = [None]      # SSP_TUNE_CACHE=<json file>: loaded once, rewritten whenever a new shape was timed
 
@@ -274,6 +289,7 @@ class Plan(object):
         self._dpack_floats = max(dsz, 1)
         self._dpack = None
         self._dgrad_tuned = False
+        self._dgrad_fallback = False     # Plan.backward's no-tuning fallback made its choices (once per plan)
         self.bn_partial = torch.empty(_lib.query('ssp_bn_bwd_blocks') * 2 * max(cs.coutp for cs in self.convs.values()), **f32)
         self._tune = device.type == 'cuda' and os.environ.get('SSP_AUTOTUNE', '1') != '0'
         if self._tune:
@@ -281,9 +297,10 @@ class Plan(object):
         # statistics / split-K workspaces follow the (tuned or heuristic) plan of each launch
         for cs in self.convs.values():
             M = cs.M
+            # (tile_m = 0 for a Winograd plan: statistics per group of tiles with the groups' pixel counts behind the pairs)
             cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
-            cs.ntile = (M + cs.tile_m - 1) // cs.tile_m
+            cs.ntile = _lib.query('ssp_conv_stats_tiles', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             # First block in training mode: conv + BN + leaky + pool with the convolution recomputed by every pass
             # instead of stored (csrc/conv_first.hip): the 32-channel full-resolution map (1.42 GB at batch 64, the
             # largest tensor of the net, written and re-read five times by the generic path) never exists.
@@ -292,7 +309,7 @@ class Plan(object):
                                   (M // 4) * cs.out.ld * 4 < (1 << 31) and device.type == 'cuda' and
                                   os.environ.get('SSP_FIRST_FUSED', '1') != '0')
             cs.first_live = False        # the last forward took the fused path (its backward must as well)
-            nstat = cs.ntile * cs.cout * 2
+            nstat = _lib.query('ssp_conv_stats_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             if cs.first_fused:
                 cs.first_groups = _lib.query('ssp_first_groups', B, cs.H, cs.W)
                 cs.first_tile = _lib.query('ssp_first_tile_pixels')
@@ -358,8 +375,8 @@ class Plan(object):
         ts += [g.t for g in self.grads.values()]
         for cs in self.convs.values():
             ts += [cs._raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None), getattr(cs, 'wbuf', None),
-                   getattr(cs, 'gbuf', None), getattr(cs, 'wino_u', None), getattr(cs, 'wino_ud', None),
-                   getattr(cs, 'wino_ws', None)]
+                   getattr(cs, 'gbuf', None), getattr(cs, 'wino_ws', None)]
+            ts += list((getattr(cs, 'wino_u', None) or {}).values()) + list((getattr(cs, 'wino_ud', None) or {}).values())
             bnp = getattr(cs, 'bnp', None)
             if bnp is not None:
                 ts.append(bnp[0])
@@ -375,17 +392,22 @@ class Plan(object):
             cs.wbuf = torch.empty(cs.cout * cs.k * cs.k * cs.cinp, dtype=torch.float32, device=self.device)
         return cs.wbuf
 
-    def _wino_u(self, cs):
-        """Winograd-transformed forward filters [16][Cout][Cin] of a layer whose forward plan is a Winograd code."""
+    def _wino_u(self, cs, tile):
+        """Winograd-transformed forward filters [(tile+2)^2][Cout][Cin] of a layer whose forward plan is a Winograd code of
+        that tile size (one buffer per tile size; the tuner drops the ones it did not choose)."""
         if getattr(cs, 'wino_u', None) is None:
-            cs.wino_u = torch.empty(16 * cs.cout * cs.cinp, dtype=torch.float32, device=self.device)
-        return cs.wino_u
+            cs.wino_u = {}
+        if tile not in cs.wino_u:
+            cs.wino_u[tile] = torch.empty((tile + 2) ** 2 * cs.cout * cs.cinp, dtype=torch.float32, device=self.device)
+        return cs.wino_u[tile]
 
-    def _wino_ud(self, cs):
-        """... and of the data-gradient operand [16][Cin][Cout] (from the flipped / transposed [Cin][tap][Cout] layout)."""
+    def _wino_ud(self, cs, tile):
+        """... and of the data-gradient operand [(tile+2)^2][Cin][Cout] (from the flipped / transposed [Cin][tap][Cout] layout)."""
         if getattr(cs, 'wino_ud', None) is None:
-            cs.wino_ud = torch.empty(16 * cs.cin * cs.coutp, dtype=torch.float32, device=self.device)
-        return cs.wino_ud
+            cs.wino_ud = {}
+        if tile not in cs.wino_ud:
+            cs.wino_ud[tile] = torch.empty((tile + 2) ** 2 * cs.cin * cs.coutp, dtype=torch.float32, device=self.device)
+        return cs.wino_ud[tile]
 
     def _wino_ws(self, cs):
         """Per-layer Winograd workspace of a layer whose FILTER GRADIENT runs in the Winograd domain (V | dM | dU, on the
@@ -394,7 +416,7 @@ class Plan(object):
         input is transformed once per step (csrc/conv_wgrad.hip ssp_conv_wgrad_wino_launch, x == NULL)."""
         if getattr(cs, 'wino_ws', None) is None:
             n = cs.wino_ws_floats
-            if cs.plan_fwd >= WINO:
+            if wino_tile(cs.plan_fwd):
                 n = max(n, _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd))
             cs.wino_ws = torch.empty(n, dtype=torch.float32, device=self.device)
         return cs.wino_ws
@@ -411,56 +433,73 @@ class Plan(object):
         tune=False (Plan.backward's fallback, entered when the forward ran without gradient bookkeeping): the saved raw
         conv outputs are live - timing / verify-after-tune launches would overwrite them (they randomise their operands)
         - so the data-gradient launches only take choices that were timed AND verified earlier in this process, else the
-        library's heuristic; a later forward with need_grad tunes them."""
+        library's heuristic; a later forward with need_grad tunes them.  The fallback's own choices are made once per plan
+        (not per backward)."""
         if self._dpack is None:
             self._dpack = torch.empty(self._dpack_floats, dtype=torch.float32, device=self.device)
-        if not self._dgrad_tuned:
-            self._dgrad_tuned = tune
-            if self._tune and tune:
-                self._autotune('dgrad')
-                self._tune_wgrad()
-            elif self._tune:
-                for cs in self.convs.values():
-                    key = self._dgrad_key(cs)
-                    cs.plan_dgrad = _TUNE_CACHE.get(key, 0) if key in _TUNE_VERIFIED else 0
-                    cs.wgrad_wino = False
-            need = 1
+        if self._dgrad_tuned or (not tune and self._dgrad_fallback):
+            return
+        self._dgrad_tuned = tune
+        self._dgrad_fallback = True
+        if self._tune and tune:
+            self._autotune('dgrad')
+            self._tune_wgrad()
+        elif self._tune:
+            wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
             for cs in self.convs.values():
-                cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
-                                                            cs.cin, cs.k, cs.plan_dgrad)
-                need = max(need, cs.ws_dgrad)
-            self._plan_bn_fusion()
-            if need > self.ws_floats:
-                torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
-                self.ws_floats = need
-                self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-                self._graph = None          # a captured inference chain holds the old workspace pointer
+                key = self._dgrad_key(cs)
+                # (the code that was verified, not just the key: a cached Winograd code that SSP_WINOGRAD=0 kept out of
+                # this process must not come back through this fallback)
+                code = _TUNE_CACHE.get(key, 0)
+                cs.plan_dgrad = code if _TUNE_VERIFIED.get(key) == code and (not wino_tile(code) or wino_on) else 0
+                cs.wgrad_wino = 0
+        need = 1
+        for cs in self.convs.values():
+            cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
+                                                        cs.cin, cs.k, cs.plan_dgrad)
+            need = max(need, cs.ws_dgrad)
+        self._plan_bn_fusion()
+        if need > self.ws_floats:
+            torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
+            self.ws_floats = need
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._graph = None          # a captured inference chain holds the old workspace pointer
+
+    def _wgrad_key(self, cs):
+        return ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld, _tune_tag())
 
     def _tune_wgrad(self):
-        """Filter gradients of the deep 3x3 layers: direct kernel or Winograd domain (ssp_conv_wgrad_wino), whichever is
-        faster on this shape; admitted only after its result on seeded operands agrees with the direct kernel's to 3e-5 of
-        the gradient's range.  Runs before the first forward of the plan (its operands are the plan's own, still empty,
-        buffers).  The choice is cached per launch shape like the igemm plans."""
+        """Filter gradients of the deep 3x3 layers: direct kernel or Winograd domain (ssp_conv_wgrad_wino_t, tile 2 or 4),
+        whichever is fastest on this shape; a Winograd form is admitted only after its result on seeded operands agrees with
+        the direct kernel's to 3e-5 of the gradient's range.  Runs before the first forward of the plan (its operands are the
+        plan's own, still empty, buffers).  The choice (0 = direct, else the tile size) is cached per launch shape like the
+        igemm plans."""
         call = _lib.call
         st = torch.cuda.current_stream().cuda_stream
         wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
         verify = os.environ.get('SSP_TUNE_VERIFY', '1') != '0'
+        tiles = tuple(int(t) for t in os.environ.get('SSP_WINO_TILES', '2,4').split(',') if t)
         gen = torch.Generator(device=self.device)
         gen.manual_seed(4321)
         n_known = len(_TUNE_CACHE)
         for cs in self.convs.values():
-            cs.wgrad_wino = False
+            cs.wgrad_wino = 0
+            cmin = min(cs.cin, cs.cout)
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
-                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and
-                    min(cs.cin, cs.cout) >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128')) and
-                    self.B * ((cs.H + 1) // 2) * ((cs.W + 1) // 2) >= 16):
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and cmin >= 64):
                 continue
-            key = ('wgrad', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.ldraw, cs.inp.ld)
-            wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout)
-            if key in _TUNE_CACHE and (key in _TUNE_VERIFIED or not verify or not _TUNE_CACHE[key]):
-                cs.wgrad_wino = bool(_TUNE_CACHE[key])
+            # tile sizes worth timing: F(2x2) from SSP_WINO_MIN_CHANNELS (128) channels on both sides, F(4x4) from 64
+            ts_ok = [t for t in tiles if cmin >= (int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128')) if t == 2 else 64) and
+                     self.B * ((cs.H + t - 1) // t) * ((cs.W + t - 1) // t) >= 16]
+            if not ts_ok:
+                continue
+            key = self._wgrad_key(cs)
+            wsn = {t: _lib.query('ssp_conv_wgrad_wino_workspace_floats_t', self.B, cs.H, cs.W, cs.cinp, cs.cout, t) for t in ts_ok}
+            cached = _TUNE_CACHE.get(key)
+            if cached is not None and (cached == 0 or (cached in ts_ok and (not verify or _TUNE_VERIFIED.get(key) == cached))):
+                cs.wgrad_wino = cached
             else:
-                ws = torch.empty(wsn, dtype=torch.float32, device=self.device)
+                ws = torch.empty(max(wsn.values()), dtype=torch.float32, device=self.device)
                 dw = [torch.zeros(cs.cout * 9 * cs.cinp, dtype=torch.float32, device=self.device) for _ in range(2)]
                 a = cs.inp
                 a.t.view(-1, a.ld)[:, a.off % a.ld:a.off % a.ld + cs.cinp].uniform_(-1.0, 1.0, generator=gen)
@@ -470,52 +509,64 @@ class Plan(object):
                     call('ssp_conv_wgrad', cs.raw.data_ptr(), cs.inp.ptr, out.data_ptr(), self.B, cs.H, cs.W, cs.cinp, cs.cout,
                          cs.ldraw, cs.inp.ld, cs.k, st)
 
-                def wino(out, cs=cs, ws=ws, wsn=wsn):
-                    call('ssp_conv_wgrad_wino', cs.raw.data_ptr(), cs.inp.ptr, out.data_ptr(), self.B, cs.H, cs.W, cs.cinp,
-                         cs.cout, cs.ldraw, cs.inp.ld, ws.data_ptr(), wsn, st)
+                def wino(out, t, cs=cs, ws=ws):
+                    call('ssp_conv_wgrad_wino_t', cs.raw.data_ptr(), cs.inp.ptr, out.data_ptr(), self.B, cs.H, cs.W, cs.cinp,
+                         cs.cout, cs.ldraw, cs.inp.ld, t, ws.data_ptr(), ws.numel(), st)
 
-                ts = []
+                def timed(fn):
+                    fn(torch.empty_like(dw[0]))
+                    best = None
+                    for _ in range(2):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fn(torch.empty_like(dw[0]))
+                        e1.record()
+                        e1.synchronize()
+                        t = e0.elapsed_time(e1)
+                        best = t if best is None else min(best, t)
+                    return best
+
+                use, t_best = 0, None
                 try:
-                    for fn, out in ((direct, dw[0]), (wino, dw[1])):
-                        fn(out)                      # also the verification pair (first call into a zeroed buffer)
-                        best = None
-                        for _ in range(2):
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            fn(torch.empty_like(out))
-                            e1.record()
-                            e1.synchronize()
-                            t = e0.elapsed_time(e1)
-                            best = t if best is None else min(best, t)
-                        ts.append(best)
-                    # verification pair: one accumulation each into zeroed buffers
+                    t_best = timed(direct)
                     dw[0].zero_()
-                    dw[1].zero_()
                     direct(dw[0])
-                    wino(dw[1])
                     den = float(dw[0].abs().max())
-                    err = float((dw[0] - dw[1]).abs().max())
-                    ok = err <= 3e-5 * max(den, 1e-30)
                 except _lib.SspError:
-                    ts, ok = [0.0, 1.0], False
-                use = bool(ok and ts[1] < 0.985 * ts[0])
-                if not ok and ts[1] < ts[0]:
-                    TUNE_REJECTED.append((key, 'wgrad_wino'))
-                    import warnings
-                    warnings.warn("singleshotpose_amd: verify-after-tune refused the Winograd filter gradient for %s" % (key,))
-                _TUNE_CACHE[key] = 1 if use else 0
-                if ok:
-                    _TUNE_VERIFIED.add(key)
+                    t_best, den = None, 1.0
+                for t in ts_ok:
+                    if t_best is None:
+                        break
+                    try:
+                        tt = timed(lambda out, t=t: wino(out, t))
+                        if not tt < 0.985 * t_best:
+                            continue
+                        # verification pair: one accumulation each into zeroed buffers
+                        dw[1].zero_()
+                        wino(dw[1], t)
+                        err = float((dw[0] - dw[1]).abs().max())
+                        ok = err <= 3e-5 * max(den, 1e-30)
+                    except _lib.SspError:
+                        continue
+                    if not ok:
+                        TUNE_REJECTED.append((key, 'wgrad_wino%d' % t))
+                        import warnings
+                        warnings.warn("singleshotpose_amd: verify-after-tune refused the Winograd F(%dx%d) filter gradient "
+                                      "for %s" % (t, t, key))
+                        continue
+                    use, t_best = t, tt
+                _TUNE_CACHE[key] = use
+                _TUNE_VERIFIED[key] = use
                 cs.wgrad_wino = use
                 del ws, dw
             if cs.wgrad_wino:
-                cs.wino_ws_floats = wsn
+                cs.wino_ws_floats = wsn[cs.wgrad_wino]
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
 
     def _dgrad_key(self, cs):
-        return ('dgrad', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld)
+        return ('dgrad', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld, _tune_tag())
 
     def _plan_bn_fusion(self):
         """BatchNorm-backward reductions folded into the producing data-gradient launch (ssp_conv_dgrad_bnbwd).
@@ -545,8 +596,7 @@ class Plan(object):
                     self.consumers[src] != [cs.ind] or scs.coutp != scs.cout or cs.cin != scs.cout or
                     cs.inp.ld != scs.ldraw or cs.inp.off != 0 or cs.cin % 4):
                 continue
-            tm = _lib.query('ssp_conv_stats_tile_m', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.plan_dgrad)
-            ntile = (cs.M + tm - 1) // tm
+            ntile = _lib.query('ssp_conv_stats_tiles', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.plan_dgrad)
             rows = min(ntile, 1024)       # more tiles than rows: folded with atomics into a buffer that stays zeroed
             cs.bn_fuse_src = scs
             scs.bnp = (torch.zeros(rows * scs.cout * 2, dtype=torch.float32, device=self.device), rows, ntile > rows)
@@ -559,9 +609,10 @@ class Plan(object):
                 src.record_stream(stream)
         _lib.call('ssp_repack_dgrad_packed' if cs.packed else 'ssp_repack_dgrad', src.data_ptr(),
                   _ptr(self._dpack, cs.doff), cs.cout, cs.cin, cs.coutp, cs.k, stream.cuda_stream)
-        if cs.plan_dgrad >= WINO:      # Winograd data-gradient plan: its filter operand is the transform of that layout
-            _lib.call('ssp_wino_filter_transform', _ptr(self._dpack, cs.doff), self._wino_ud(cs).data_ptr(), cs.cin,
-                      cs.coutp, stream.cuda_stream)
+        tile = wino_tile(cs.plan_dgrad)
+        if tile:      # Winograd data-gradient plan: its filter operand is the transform of that layout
+            _lib.call('ssp_wino_filter_transform_t', _ptr(self._dpack, cs.doff), self._wino_ud(cs, tile).data_ptr(), cs.cin,
+                      cs.coutp, tile, stream.cuda_stream)
 
     # ------------------------------------------------------------------ per-shape tile / split selection
     def _autotune(self, which):
@@ -596,13 +647,33 @@ class Plan(object):
         # transform passes - timed against the direct plans on the 3x3 layers with >= 128 channels on both sides (with 64
         # the tuner never picked one: the transforms of the wide maps cost more than the short-K GEMMs save; measured,
         # profiles/r03_step_ab_winograd.txt).  SSP_WINOGRAD=0 turns them off, SSP_WINO_MIN_CHANNELS moves the threshold.
-        wino_cands = (WINO + 6413, WINO + 6414, WINO + 12813, WINO + 12814)
+        # F(4x4, 3x3) candidates (WINO4): 36/144 of the multiplies and 2.25 instead of 4 transform floats per pixel, so they
+        # are timed from 64 channels up (SSP_WINO_TILES=2 or =4 restricts the tile sizes tried).
+        gemm_cands = (6413, 6414, 12813, 12814)
         wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
         wino_min = int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128'))
+        wino_tiles = tuple(int(t) for t in os.environ.get('SSP_WINO_TILES', '2,4').split(',') if t)
 
-        def wino_ok(cs, which):
-            return (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
-                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and min(cs.cin, cs.cout) >= wino_min)
+        def wino_bases(cs, which):
+            """Plan-code bases (WINO / WINO4) of the Winograd forms worth timing on this launch."""
+            if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0):
+                return ()
+            n_out = cs.cout if which == 'fwd' else cs.cin      # the batched GEMM kernel wants more than 64 output columns
+            bases = []
+            if 2 in wino_tiles and min(cs.cin, cs.cout) >= wino_min and n_out > 64:
+                bases.append(WINO)
+            if 4 in wino_tiles and min(cs.cin, cs.cout) >= 64 and n_out > 64:
+                bases.append(WINO4)
+            return tuple(bases)
+
+        def wino_codes(cs, which, small=False):
+            codes = []
+            for base in wino_bases(cs, which):
+                codes += [base + c for c in gemm_cands]
+                if small:      # small grids - batch-1 inference: also the 8-slot latency ring, as for the direct plans
+                    codes += [base + 6418, base + 12818]
+            return tuple(codes)
         def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x4 mid, none big)
             mc = cs.M * max(cs.coutp, cs.cinp)
             need = 9 * mc if mc <= (1 << 21) else (4 * mc if mc <= (1 << 25) else 1)
@@ -611,13 +682,14 @@ class Plan(object):
             need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, 0))
             if not cs.first:
                 need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, 0))
-            if wino_ok(cs, which):
-                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, wino_cands[0]))
-                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, wino_cands[0]))
+            for base in wino_bases(cs, 'fwd') + wino_bases(cs, 'dgrad'):
+                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, base + 6413))
+                need = max(need, _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, base + 6413))
             return need
         max_ws = max(ws_need(cs) for cs in elig)
         ws = torch.empty(max_ws, **f32)
-        stats = torch.empty(max(((cs.M + 63) // 64) * cs.cout * 2 for cs in elig), **f32) if which == 'fwd' else None
+        # statistics scratch: the finest tiling any candidate uses (Winograd plans: groups of 16 tiles, counts behind the pairs)
+        stats = torch.empty(max(((cs.M + 15) // 16 + 16) * (cs.cout * 2 + 1) for cs in elig), **f32) if which == 'fwd' else None
         gscratch = torch.zeros(max(cs.M * max(cs.inp.ld, cs.ldraw) for cs in elig), **f32) if which == 'dgrad' else None
         verify = os.environ.get('SSP_TUNE_VERIFY', '1') != '0'
         gen = torch.Generator(device=self.device)
@@ -626,17 +698,17 @@ class Plan(object):
         def best_of(launch, mn, key, extra=()):
             keep = True
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
-                if _TUNE_CACHE[key] < WINO or extra:
+                if not wino_tile(_TUNE_CACHE[key]) or _TUNE_CACHE[key] in extra:
                     return _TUNE_CACHE[key]
-                keep = False             # a cached Winograd choice with Winograd plans switched off: time the direct plans,
-                                         # leave the cache entry alone
+                keep = False             # a cached Winograd choice whose family is switched off in this process: time the
+                                         # other plans, leave the cache entry alone
             best, best_t = 0, None
             # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
             # deep K splits put every CU on the weight stream
             deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4, 8)) \
                 if mn <= (1 << 21) else ()
             for code in cands + (lat if mn <= (1 << 23) else ()) + deep + tuple(extra):
-                if code < WINO and ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
+                if not wino_tile(code) and ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
                 try:
                     launch(code)
@@ -660,7 +732,7 @@ class Plan(object):
         def admitted(code, key, launch, out_of, operands, bn_of=None, prep=None):
             """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands.  A Winograd
             plan is another ALGORITHM, not another summation order: its bar is 3e-5 of the output's range (measured ~1e-6)."""
-            if code == 0 or not verify or key in _TUNE_VERIFIED:
+            if code == 0 or not verify or _TUNE_VERIFIED.get(key) == code:
                 return code
             # Operands are the plan's own buffers (they hold no data yet: tuning runs before the first forward, and
             # Plan.backward's fallback never tunes).  Only the columns a launch owns are randomised: the channel padding of
@@ -669,7 +741,7 @@ class Plan(object):
                 (t[0].view(-1, t[1])[:, t[2]:t[2] + t[3]] if isinstance(t, tuple) else t).uniform_(-1.0, 1.0, generator=gen)
             if prep is not None:
                 prep()                # operands changed: derived operands (Winograd-transformed filters) follow
-            bar = 3e-5 if code >= WINO else 1e-5
+            bar = 3e-5 if wino_tile(code) else 1e-5
             res = []
             for c in (0, code):
                 launch(c)
@@ -684,7 +756,7 @@ class Plan(object):
                 if not (err <= bar * max(den, 1e-30)):      # also false for NaN
                     ok = False
             if ok:
-                _TUNE_VERIFIED.add(key)
+                _TUNE_VERIFIED[key] = code
                 return code
             TUNE_REJECTED.append((key, code))
             _TUNE_CACHE[key] = 0
@@ -697,15 +769,16 @@ class Plan(object):
             if which == 'fwd' and cs.cout > 64:
                 # operand contents are irrelevant for timing: a channels-last-sized parameter stands in for itself
                 wop = cs.conv.weight if cs.cinp == cs.cin else self._wbuf(cs)
-                key = ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn))
+                key = ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn), _tune_tag())
 
-                wino = wino_ok(cs, which)
+                wc = wino_codes(cs, which, cs.M * cs.coutp <= (1 << 23))
 
-                def prep_f(cs=cs, wop=wop):
-                    call('ssp_wino_filter_transform', wop.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp, st)
+                def prep_f(tile, cs=cs, wop=wop):
+                    call('ssp_wino_filter_transform_t', wop.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp,
+                         tile, st)
 
                 def launch(code, cs=cs, wop=wop):
-                    wt = self._wino_u(cs) if code >= WINO else wop
+                    wt = self._wino_u(cs, wino_tile(code)) if wino_tile(code) else wop
                     call('ssp_conv_fwd', cs.inp.ptr, wt.data_ptr(), cs.raw.data_ptr(), None,
                          stats.data_ptr() if cs.bn else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,
                          cs.k, 0, code, ws.data_ptr(), max_ws, st)
@@ -713,47 +786,48 @@ class Plan(object):
                 def bn_of(code, cs=cs):
                     # batch statistics from this plan's per-tile (mean, M2) partials: mean and 1/std per channel
                     tm = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, code)
+                    nt = _lib.query('ssp_conv_stats_tiles', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, code)
                     tmp = torch.zeros(8, cs.coutp, **f32)
                     tmp[0].fill_(1.0)
                     tmp[3].fill_(1.0)
-                    call('ssp_bn_fwd_finalize', stats.data_ptr(), (cs.M + tm - 1) // tm, tm, cs.M, cs.cout,
+                    call('ssp_bn_fwd_finalize', stats.data_ptr(), nt, tm, cs.M, cs.cout,
                          tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), tmp[3].data_ptr(), BN_MOMENTUM,
                          BN_EPS, tmp[4].data_ptr(), tmp[5].data_ptr(), tmp[6].data_ptr(), tmp[7].data_ptr(), st)
                     return [tmp[4, :cs.cout].clone(), tmp[5, :cs.cout].clone()]
 
-                if wino and key not in _TUNE_CACHE:
-                    prep_f()
-                # (small grids - batch-1 inference: also the 8-slot latency ring for the batched GEMM, as for the direct plans)
-                wc = (wino_cands + ((WINO + 6418, WINO + 12818) if cs.M * cs.coutp <= (1 << 23) else ())) if wino else ()
+                if wc and key not in _TUNE_CACHE:
+                    for t in sorted(set(wino_tile(c) for c in wc)):
+                        prep_f(t)
                 code = best_of(launch, cs.M * cs.coutp, key, wc)
                 a = cs.inp
                 cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [(a.t, a.ld, a.off % a.ld, cs.cinp)] +
                                        ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None,
-                                       prep_f if code >= WINO else None)
-                if cs.plan_fwd < WINO:
-                    cs.wino_u = None          # not chosen: the transformed-filter buffer goes back to the allocator
+                                       (lambda code=code: prep_f(wino_tile(code))) if wino_tile(code) else None)
+                # not chosen: the transformed-filter buffers go back to the allocator
+                cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
             if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
                 key = self._dgrad_key(cs)
                 wslice = self._dpack[cs.doff:cs.doff + cs.cinp * cs.k * cs.k * cs.coutp]
 
-                wino = wino_ok(cs, which)
+                wc = wino_codes(cs, which)
 
-                def prep_d(cs=cs):
-                    call('ssp_wino_filter_transform', _ptr(self._dpack, cs.doff), self._wino_ud(cs).data_ptr(), cs.cin,
-                         cs.coutp, st)
+                def prep_d(tile, cs=cs):
+                    call('ssp_wino_filter_transform_t', _ptr(self._dpack, cs.doff), self._wino_ud(cs, tile).data_ptr(), cs.cin,
+                         cs.coutp, tile, st)
 
                 def launch(code, cs=cs):
-                    wt = self._wino_ud(cs).data_ptr() if code >= WINO else _ptr(self._dpack, cs.doff)
+                    wt = self._wino_ud(cs, wino_tile(code)).data_ptr() if wino_tile(code) else _ptr(self._dpack, cs.doff)
                     call('ssp_conv_dgrad', cs.raw.data_ptr(), wt, gscratch.data_ptr(), B, cs.H,
                          cs.W, cs.coutp, cs.cin, cs.ldraw, cs.inp.ld, cs.k, 0, code, ws.data_ptr(), max_ws, st)
 
-                if wino and key not in _TUNE_CACHE:
-                    prep_d()
-                code = best_of(launch, cs.M * cs.cinp, key, wino_cands if wino else ())
+                if wc and key not in _TUNE_CACHE:
+                    for t in sorted(set(wino_tile(c) for c in wc)):
+                        prep_d(t)
+                code = best_of(launch, cs.M * cs.cinp, key, wc)
                 cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld],
-                                         [(cs.raw, cs.ldraw, 0, cs.cout), wslice], None, prep_d if code >= WINO else None)
-                if cs.plan_dgrad < WINO:
-                    cs.wino_ud = None
+                                         [(cs.raw, cs.ldraw, 0, cs.cout), wslice], None,
+                                         (lambda code=code: prep_d(wino_tile(code))) if wino_tile(code) else None)
+                cs.wino_ud = {t: b for t, b in (getattr(cs, 'wino_ud', None) or {}).items() if t == wino_tile(cs.plan_dgrad)}
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
@@ -797,7 +871,7 @@ class Plan(object):
         # step; in eval when a parameter version / the weights epoch moved), on the side stream like the repacks
         wino = []
         for cs in self.convs.values():
-            if cs.plan_fwd >= WINO:
+            if wino_tile(cs.plan_fwd):
                 wt = cs.conv.weight
                 wkey = (wt.data_ptr(), wt._version, _WEIGHTS_EPOCH[0])
                 if inline_repack or training or self.wino_version.get(cs.ind) != wkey:
@@ -806,7 +880,8 @@ class Plan(object):
         if inline_repack:
             for cs, _ in wino:       # graph capture: part of the captured chain
                 src = cs.conv.weight if cs.packed else self._wbuf(cs)
-                call('ssp_wino_filter_transform', src.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp, st)
+                tile = wino_tile(cs.plan_fwd)
+                call('ssp_wino_filter_transform_t', src.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp, tile, st)
                 self.wino_version.pop(cs.ind, None)
             wino = []
         if stale or need_grad or wino:
@@ -829,8 +904,9 @@ class Plan(object):
             if wino:
                 for cs, wkey in wino:
                     src = cs.conv.weight if cs.packed else self._wbuf(cs)
-                    call('ssp_wino_filter_transform', src.data_ptr(), self._wino_u(cs).data_ptr(), cs.cout, cs.cinp,
-                         side.cuda_stream)
+                    tile = wino_tile(cs.plan_fwd)
+                    call('ssp_wino_filter_transform_t', src.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp,
+                         tile, side.cuda_stream)
                     self.wino_version[cs.ind] = wkey
                 ev = side.record_event()
                 for cs, _ in wino:
@@ -872,8 +948,8 @@ class Plan(object):
                              v[1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), st)
                         self.bnversion[cs.ind] = None if inline_repack else bkey
                 wptr = cs.conv.weight.data_ptr() if cs.packed else self._wbuf(cs).data_ptr()
-                if cs.plan_fwd >= WINO:
-                    wptr = self._wino_u(cs).data_ptr()
+                if wino_tile(cs.plan_fwd):
+                    wptr = self._wino_u(cs, wino_tile(cs.plan_fwd)).data_ptr()
                 cs.first_live = False
                 if cs.first_fused and not cs.packed and (training or not need_grad):
                     # training: statistics pass + apply pass; inference: the apply pass alone with the running-statistics
@@ -899,7 +975,7 @@ class Plan(object):
                     continue
                 ws_t = self.ws
                 cs.v_live = False
-                if (need_grad and cs.plan_fwd >= WINO and getattr(cs, 'wgrad_wino', False) and
+                if (need_grad and wino_tile(cs.plan_fwd) and getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and
                         os.environ.get('SSP_WINO_SHARE_V', '1') != '0'):
                     ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
                     cs.v_live = True
@@ -1123,10 +1199,10 @@ class Plan(object):
                     out_grads[id(cs.conv.bias)] = db
                 side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
                 gw = gview(cs.conv.weight, cs.packed)
-                if cs.packed and getattr(cs, 'wgrad_wino', False):
+                if cs.packed and getattr(cs, 'wgrad_wino', 0):
                     wws = self._wino_ws(cs)
-                    call('ssp_conv_wgrad_wino', dy_ptr, None if getattr(cs, 'v_live', False) else cs.inp.ptr, gw.data_ptr(),
-                         B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld, cs.inp.ld, wws.data_ptr(), wws.numel(), st2)
+                    call('ssp_conv_wgrad_wino_t', dy_ptr, None if getattr(cs, 'v_live', False) else cs.inp.ptr, gw.data_ptr(),
+                         B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld, cs.inp.ld, cs.wgrad_wino, wws.data_ptr(), wws.numel(), st2)
                     cs.v_live = False
                 elif cs.packed:       # accumulate in place: the gradient has the parameter's channels-last layout
                     call('ssp_conv_wgrad', dy_ptr, cs.inp.ptr, gw.data_ptr(), B, cs.H, cs.W, cs.cinp, cs.cout, dy_ld,
@@ -1143,7 +1219,8 @@ class Plan(object):
                     src = producer_of(cs.inp)
                     gin = self._grad_buf(src, cs.inp)
                     scs = getattr(cs, 'bn_fuse_src', None)
-                    dwt = self._wino_ud(cs).data_ptr() if cs.plan_dgrad >= WINO else _ptr(self._dpack, cs.doff)
+                    dwt = (self._wino_ud(cs, wino_tile(cs.plan_dgrad)).data_ptr() if wino_tile(cs.plan_dgrad)
+                           else _ptr(self._dpack, cs.doff))
                     if scs is not None and src not in written:
                         sv = scs.vec
                         call('ssp_conv_dgrad_bnbwd', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W,

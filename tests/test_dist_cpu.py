@@ -28,17 +28,20 @@ def _worker(rank, world, port, q):
     red = GradReducer(None, world, bucket_bytes=40000 * 4, tail_bytes=0)
     results = []
     flat = torch.empty(total)
-    for step in range(3):                                   # the SAME flat buffer every backward, as Plan.backward reuses it
+    for step in range(4):                                   # the SAME flat buffer every backward, as Plan.backward reuses it
         g = torch.Generator().manual_seed(100 * step + rank)
         flat.copy_(torch.randn(total, generator=g))
         local = flat.clone()
         red.tail_elems = 71000 if step == 1 else 0          # step 1: the tail rule closes a bucket early
+        red.bucket_elems = 10 ** 9 if step == 3 else 40000  # step 3: nothing reaches a bucket - only an OPEN bucket is left
         red.begin(flat)
         for i in range(len(sizes)):
             red.layer_done(flat, int(offs[i]), int(offs[i + 1]))
         if step < 2:
             red.all_reduce()
         else:                                               # a backward that is never joined: the next begin() joins it
+            if step == 3:
+                assert not red._pending and not red.launched    # (no launched bucket to remind it: the open range must)
             red.begin(flat)
             assert not red._pending
             red.all_reduce()
@@ -61,11 +64,11 @@ def test_gradient_all_reduce_sum_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for step in range(3):
+    for step in range(4):
         expected = out[0][step][0] + out[1][step][0]        # SUM, not mean (reference loss is a batch sum)
         for r in range(world):
             assert np.allclose(out[r][step][1], expected, rtol=0, atol=1e-6)
-        if step == 2:
+        if step >= 2:
             continue                                        # joined by begin(): the bucket list was reset
         buckets = out[0][step][2]
         assert buckets == out[1][step][2]

@@ -70,3 +70,30 @@ def test_run_pinned_pins_the_wall_clock_seed(tmp_path):
     outs = [subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'run_pinned.py'), str(script)], cwd=str(tmp_path),
                            stdout=subprocess.PIPE, text=True, check=True).stdout for _ in range(2)]
     assert outs[0] == outs[1] and 'PROBE' in outs[0]
+
+
+def test_array_shim_honours_numpy2_copy_semantics():
+    """dropin/_compat.py: np.array(cpu_tensor) must not alias the tensor (NumPy 2 passes copy=True to __array__ and does
+    not copy on top of what it gets back); np.asarray may; copy=False on a tensor that has to be moved raises."""
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import _compat\n"
+        "t = torch.arange(4, dtype=torch.float32)\n"
+        "a = np.array(t)\n"
+        "a[0] = 99\n"
+        "assert t[0].item() == 0.0, 'np.array(t) aliases the tensor'\n"
+        "assert not np.shares_memory(np.array(t), t.numpy())\n"
+        "b = np.asarray(t)\n"
+        "assert np.shares_memory(b, t.numpy())\n"
+        "g = torch.ones(3, requires_grad=True)\n"
+        "assert np.array(g).tolist() == [1.0, 1.0, 1.0]\n"
+        "try:\n"
+        "    g.__array__(copy=False)\n"
+        "    raise SystemExit('copy=False on a grad tensor did not raise')\n"
+        "except ValueError:\n"
+        "    pass\n"
+        "assert np.array(t, dtype=np.float64).dtype == np.float64\n"
+        "print('ok')\n") % os.path.join(ROOT, 'dropin')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr

@@ -1,4 +1,4 @@
-"""Winograd F(2x2, 3x3) plans of the conv entry points (csrc/conv_wino.hip) through the C ABI against PyTorch-CPU
+"""Winograd F(2x2, 3x3) and F(4x4, 3x3) plans of the conv entry points (csrc/conv_wino.hip) through the C ABI against PyTorch-CPU
 F.conv2d (what nn.Conv2d runs in the reference, darknet.py:154-160) and against the library's direct plan: forward
 (raw output, BatchNorm statistics, bias, accumulate, sliced output), the eval-mode affine form, the data gradient (plain,
 accumulating, with the fused BatchNorm-backward reductions), odd and even maps, ragged tiles.  Same 1e-4 bar as every
@@ -12,7 +12,12 @@ from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-WINO = 9006413      # Winograd, 64-row GEMM tiles, 3-slot ring
+WINO = 9006413      # Winograd F(2x2), 64-row GEMM tiles, 3-slot ring
+WINO4 = 8006413     # Winograd F(4x4), same GEMM tiles
+
+
+def _tile(plan):
+    return 4 if plan < 9000000 else 2
 
 
 def _imports():
@@ -21,9 +26,9 @@ def _imports():
     return G, _lib
 
 
-def _wino_filters(G, _lib, w9, rows, K):
-    U = torch.empty(16 * rows * K, dtype=torch.float32, device=G.dev())
-    _lib.call('ssp_wino_filter_transform', w9.data_ptr(), U.data_ptr(), rows, K, G.stream())
+def _wino_filters(G, _lib, w9, rows, K, tile=2):
+    U = torch.empty((tile + 2) ** 2 * rows * K, dtype=torch.float32, device=G.dev())
+    _lib.call('ssp_wino_filter_transform_t', w9.data_ptr(), U.data_ptr(), rows, K, tile, G.stream())
     return U
 
 
@@ -35,6 +40,13 @@ CASES = [
     (5, 7, 9, 32, 160, 0, False, WINO),            # tiny odd map, ragged M
     (64, 13, 13, 256, 512, 0, False, WINO),        # benchmark grid: 3136 tiles per transform position
     (2, 1, 5, 64, 128, 0, False, WINO),            # a single image row
+    (2, 13, 13, 64, 128, 0, False, WINO4),         # F(4x4): 13 = 3 tiles + 1 pixel: the last tile row / column holds one
+    (3, 14, 10, 128, 96, 32, True, WINO4),         # bias, sliced output, ragged tiles both ways
+    (1, 21, 21, 256, 256, 0, False, 8012814),      # valid.py's grid
+    (5, 7, 9, 32, 160, 0, False, WINO4),
+    (64, 13, 13, 256, 512, 0, False, WINO4),       # benchmark grid: 1024 tiles per transform position
+    (2, 1, 5, 64, 128, 0, False, WINO4),
+    (4, 52, 52, 128, 256, 0, False, WINO4),        # 13 x 13 exact tiles, the K = 128 GEMMs of layers 8 / 10
 ]
 
 
@@ -50,7 +62,7 @@ def test_wino_conv_fwd(B, H, W, Cin, Cout, xout, bias, plan):
     off = xout // 2
     xd = G.to_nhwc(x)
     wd = G.pack_fwd(w)
-    U = _wino_filters(G, _lib, wd, Cout, Cin)
+    U = _wino_filters(G, _lib, wd, Cout, Cin, _tile(plan))
     bd = bvec.to(G.dev()) if bias else None
     M = B * H * W
 
@@ -65,9 +77,9 @@ def test_wino_conv_fwd(B, H, W, Cin, Cout, xout, bias, plan):
         torch.cuda.synchronize()
         return out
 
-    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, 3, plan)
-    ntile = (M + tile_m - 1) // tile_m
-    stats = torch.zeros(ntile * Cout * 2, dtype=torch.float32, device=G.dev())
+    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, 3, plan)      # 0: counted format
+    ntile = _lib.query('ssp_conv_stats_tiles', B, H, W, Cin, Cout, 3, plan)
+    stats = torch.zeros(_lib.query('ssp_conv_stats_floats', B, H, W, Cin, Cout, 3, plan), dtype=torch.float32, device=G.dev())
     out = run(plan, U, stats=stats)
     got = G.from_nhwc(out, B, Cout, H, W, off)
     direct = G.from_nhwc(run(0, wd), B, Cout, H, W, off)
@@ -93,7 +105,8 @@ def test_wino_conv_fwd(B, H, W, Cin, Cout, xout, bias, plan):
                                    (1 / torch.sqrt(r64.var(dim=(0, 2, 3), unbiased=False) + 1e-4)).numpy(), rtol=1e-4)
 
 
-def test_wino_conv_fwd_affine_eval_block():
+@pytest.mark.parametrize("WINO", [WINO, WINO4])
+def test_wino_conv_fwd_affine_eval_block(WINO):
     """Inference form: BatchNorm affine + leaky applied by the finishing pass (ssp_conv_fwd_affine with a Winograd plan)."""
     G, _lib = _imports()
     B, H, W, Cin, Cout = 1, 21, 21, 128, 256
@@ -104,7 +117,7 @@ def test_wino_conv_fwd_affine_eval_block():
     sh = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
     ref = F.leaky_relu(F.conv2d(x, w, None, padding=1) * sc[None, :, None, None] + sh[None, :, None, None], 0.1)
     xd, wd = G.to_nhwc(x), G.pack_fwd(w)
-    U = _wino_filters(G, _lib, wd, Cout, Cin)
+    U = _wino_filters(G, _lib, wd, Cout, Cin, _tile(WINO))
     wsn = _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, WINO)
     ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
     out = torch.empty(B * H * W, Cout, dtype=torch.float32, device=G.dev())
@@ -115,8 +128,9 @@ def test_wino_conv_fwd_affine_eval_block():
     assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("WINO", [WINO, WINO4])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 128, 256), (3, 10, 14, 256, 128), (64, 13, 13, 128, 512)])
-def test_wino_conv_dgrad(B, H, W, Cin, Cout):
+def test_wino_conv_dgrad(B, H, W, Cin, Cout, WINO):
     """Data gradient with a Winograd plan: filters from the ssp_repack_dgrad layout; plain, accumulating, and with the
     BatchNorm-backward reductions of the producing block folded into the finishing pass (ssp_conv_dgrad_bnbwd)."""
     G, _lib = _imports()
@@ -128,7 +142,7 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout):
     want = x.grad
     dyd = G.to_nhwc(dy)
     wd = G.pack_dgrad(w, Cout)                                   # [Cin][tap'][Cout]
-    U = _wino_filters(G, _lib, wd, Cin, Cout)
+    U = _wino_filters(G, _lib, wd, Cin, Cout, _tile(WINO))
     M = B * H * W
     wsn = _lib.query('ssp_conv_workspace_floats', B, H, W, Cout, Cin, 3, WINO)
     ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
@@ -148,8 +162,7 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout):
     shift = torch.from_numpy(rs.standard_normal(Cin).astype(np.float32) * 0.3)
     mean = torch.from_numpy(rs.standard_normal(Cin).astype(np.float32) * 0.1)
     invstd = torch.from_numpy(rs.uniform(0.5, 2.0, Cin).astype(np.float32))
-    tile_m = _lib.query('ssp_conv_stats_tile_m', B, H, W, Cout, Cin, 3, WINO)
-    rows = (M + tile_m - 1) // tile_m
+    rows = _lib.query('ssp_conv_stats_tiles', B, H, W, Cout, Cin, 3, WINO)
     part = torch.zeros(rows * Cin * 2, dtype=torch.float32, device=G.dev())
     rawd = G.to_nhwc(raw)
     dv = [t.to(G.dev()) for t in (scale, shift, mean, invstd)]
@@ -168,8 +181,10 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout):
     assert rel_err(got[:, 0].numpy(), s1.numpy()) < TOL and rel_err(got[:, 1].numpy(), s2.numpy()) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 13, 13, 128, 256), (3, 10, 14, 256, 64), (64, 13, 13, 256, 512), (16, 7, 9, 64, 192)])
-def test_wino_conv_wgrad(B, H, W, Cin, Cout):
+@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 13, 13, 128, 256), (3, 10, 14, 256, 64), (64, 13, 13, 256, 512), (16, 7, 9, 64, 192),
+                                            (64, 13, 13, 512, 1024)])
+def test_wino_conv_wgrad(B, H, W, Cin, Cout, tile):
     """Filter gradient in the Winograd domain (ssp_conv_wgrad_wino) against autograd of F.conv2d and against the direct
     kernel; accumulates into dw (a second call doubles it)."""
     G, _lib = _imports()
@@ -179,8 +194,9 @@ def test_wino_conv_wgrad(B, H, W, Cin, Cout):
     dy = torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32))
     F.conv2d(x, w, None, padding=1).backward(dy)
     xd, dyd = G.to_nhwc(x), G.to_nhwc(dy)
-    wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout)
-    ws = torch.empty(wsn, dtype=torch.float32, device=G.dev())
+    wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile)
+    # (NaN-poisoned: the transform-domain gradient inside is written, not accumulated, whatever the launch's split)
+    ws = torch.full((wsn,), float('nan'), dtype=torch.float32, device=G.dev())
     dwp = torch.zeros(Cout * 9 * Cin, dtype=torch.float32, device=G.dev())
 
     def unpack(buf):
@@ -189,19 +205,20 @@ def test_wino_conv_wgrad(B, H, W, Cin, Cout):
         torch.cuda.synchronize()
         return gw.cpu().numpy()
 
-    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin,
+    _lib.call('ssp_conv_wgrad_wino_t', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, tile,
               ws.data_ptr(), wsn, G.stream())
     got = unpack(dwp)
     direct = torch.zeros_like(dwp)
     _lib.call('ssp_conv_wgrad', dyd.data_ptr(), xd.data_ptr(), direct.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, 3, G.stream())
     print('winograd wgrad vs autograd %.2e, vs the direct kernel %.2e' % (rel_err(got, w.grad.numpy()), rel_err(got, unpack(direct))))
     assert rel_err(got, w.grad.numpy()) < TOL
-    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin,
+    _lib.call('ssp_conv_wgrad_wino_t', dyd.data_ptr(), xd.data_ptr(), dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, tile,
               ws.data_ptr(), wsn, G.stream())
     assert rel_err(unpack(dwp), 2 * w.grad.numpy()) < TOL
 
 
-def test_wino_wgrad_reuses_the_forward_launch_transformed_input():
+@pytest.mark.parametrize("WINO", [WINO, WINO4])
+def test_wino_wgrad_reuses_the_forward_launch_transformed_input(WINO):
     """ssp_conv_wgrad_wino with x == NULL: the transformed input V left at the head of the workspace by the layer's own
     Winograd forward launch (same buffer) is used instead of transforming x again - same gradient as with x."""
     G, _lib = _imports()
@@ -212,16 +229,17 @@ def test_wino_wgrad_reuses_the_forward_launch_transformed_input():
     dy = torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32))
     F.conv2d(x, w, None, padding=1).backward(dy)
     xd, dyd = G.to_nhwc(x), G.to_nhwc(dy)
+    tile = _tile(WINO)
     wd = G.pack_fwd(w.detach())
-    U = _wino_filters(G, _lib, wd, Cout, Cin)
-    wsn = max(_lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout),
+    U = _wino_filters(G, _lib, wd, Cout, Cin, tile)
+    wsn = max(_lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile),
               _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, WINO))
     ws = torch.full((wsn,), float('nan'), dtype=torch.float32, device=G.dev())
     out = torch.empty(B * H * W, Cout, dtype=torch.float32, device=G.dev())
     _lib.call('ssp_conv_fwd', xd.data_ptr(), U.data_ptr(), out.data_ptr(), None, None, B, H, W, Cin, Cout, Cin, Cout, 3, 0, WINO,
               ws.data_ptr(), wsn, G.stream())
     dwp = torch.zeros(Cout * 9 * Cin, dtype=torch.float32, device=G.dev())
-    _lib.call('ssp_conv_wgrad_wino', dyd.data_ptr(), None, dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, ws.data_ptr(), wsn,
+    _lib.call('ssp_conv_wgrad_wino_t', dyd.data_ptr(), None, dwp.data_ptr(), B, H, W, Cin, Cout, Cout, Cin, tile, ws.data_ptr(), wsn,
               G.stream())
     gw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=G.dev())
     _lib.call('ssp_unpack_grad', dwp.data_ptr(), gw.data_ptr(), Cout, Cin, Cin, 3, G.stream())

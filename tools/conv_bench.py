@@ -13,7 +13,7 @@ from singleshotpose_amd import _lib
 # name: (H, Cin, Cout, R) of yolo-pose.cfg layers at 416x416
 CASES = {
     'l0': (416, 4, 32, 3), 'l2': (208, 32, 64, 3), 'l4': (104, 64, 128, 3), 'l5': (104, 128, 64, 1),
-    'l8': (52, 128, 256, 3), 'l9': (52, 256, 128, 1), 'l12': (26, 256, 512, 3), 'l13': (26, 512, 256, 1),
+    'l6': (104, 64, 128, 3), 'l8': (52, 128, 256, 3), 'l9': (52, 256, 128, 1), 'l12': (26, 256, 512, 3), 'l13': (26, 512, 256, 1),
     'l18': (13, 512, 1024, 3), 'l19': (13, 1024, 512, 1), 'l23': (13, 1024, 1024, 3), 'l29': (13, 1280, 1024, 3),
     'l30': (13, 1024, 20, 1), 'l26': (26, 512, 64, 1),
 }
@@ -80,20 +80,21 @@ def run_cases(args, dev, st, B):
         out = torch.empty(M * coutp, device=dev)
         dx = torch.empty(M * Cin, device=dev)
         dw = torch.zeros(Cout * R * R * Cin, device=dev)
-        stats = torch.empty(((M + 63) // 64) * Cout * 2, device=dev)  # sized for the smallest M tile any variant uses
+        stats = torch.empty(((M + 15) // 16 + 16) * (Cout * 2 + 1), device=dev)  # sized for the finest statistics tiling any plan uses
         flop = 2.0 * M * Cout * R * R * Cin
         for plan in [int(v) for v in args.plans.split(',')]:
-            wino = plan >= 9000000
-            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout <= 64 or Cin <= 64):
+            tile = _lib.query('ssp_conv_plan_wino_tile', plan)      # 2 / 4: Winograd F(2x2) / F(4x4) plan, 0: direct
+            wino = tile > 0
+            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout <= 64 or Cin < 64):
                 continue
             wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, plan), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, plan))
             ws = torch.empty(wsn, device=dev)
             wf, wdd = w, wd
             if wino:
-                wf = torch.empty(16 * Cout * Cin, device=dev)
-                wdd = torch.empty(16 * Cin * coutp, device=dev)
-                _lib.call('ssp_wino_filter_transform', w.data_ptr(), wf.data_ptr(), Cout, Cin, st)
-                _lib.call('ssp_wino_filter_transform', wd.data_ptr(), wdd.data_ptr(), Cin, coutp, st)
+                wf = torch.empty((tile + 2) ** 2 * Cout * Cin, device=dev)
+                wdd = torch.empty((tile + 2) ** 2 * Cin * coutp, device=dev)
+                _lib.call('ssp_wino_filter_transform_t', w.data_ptr(), wf.data_ptr(), Cout, Cin, tile, st)
+                _lib.call('ssp_wino_filter_transform_t', wd.data_ptr(), wdd.data_ptr(), Cin, coutp, tile, st)
             fns = {
                 'fwd': lambda: _lib.call('ssp_conv_fwd', x.data_ptr(), wf.data_ptr(), out.data_ptr(), None, stats.data_ptr(),
                                          B, H, W, Cin, Cout, Cin, coutp, R, 0, plan, ws.data_ptr(), wsn, st),
@@ -101,16 +102,17 @@ def run_cases(args, dev, st, B):
                                            coutp, Cin, R, 0, plan, ws.data_ptr(), wsn, st),
                 'wgrad': lambda: _lib.call('ssp_conv_wgrad', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
                                            coutp, Cin, R, st),
-                'wgradw': lambda: _lib.call('ssp_conv_wgrad_wino', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
-                                            coutp, Cin, wsw.data_ptr(), wsw.numel(), st),
-                'wfilt': lambda: _lib.call('ssp_wino_filter_transform', w.data_ptr(), wf.data_ptr(), Cout, Cin, st),
+                # (the Winograd filter gradient of the tile size of THIS row's plan: direct rows skip it)
+                'wgradw': lambda: _lib.call('ssp_conv_wgrad_wino_t', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
+                                            coutp, Cin, tile, wsw.data_ptr(), wsw.numel(), st),
+                'wfilt': lambda: _lib.call('ssp_wino_filter_transform_t', w.data_ptr(), wf.data_ptr(), Cout, Cin, tile, st),
             }
             wsw = ws
-            if 'wgradw' in args.ops.split(',') and R == 3 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 64 and Cout >= 64:
-                wsw = torch.empty(_lib.query('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout), device=dev)
+            if 'wgradw' in args.ops.split(',') and wino and R == 3 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 64 and Cout >= 64:
+                wsw = torch.empty(_lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile), device=dev)
             line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d plan %7d |' % (name, H, Cin, Cout, R, plan)
             for op in args.ops.split(','):
-                if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op in ('wgrad', 'wgradw') and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
+                if (op == 'dgrad' and (name == 'l0' or (wino and Cin <= 64))) or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
                     continue
                 fn = fns[op]
                 for _ in range(3):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Prints the autotuned igemm plan of every conv launch of cfg/yolo-pose.cfg at a given batch / size
-(plan code = tail*100000 + tile_rows*100 + ksplit*10 + ring_slots; 0 = library heuristic; 9xxxxxx = Winograd)."""
+(plan code = tail*100000 + tile_rows*100 + ksplit*10 + ring_slots; 0 = library heuristic; 9xxxxxx = Winograd F(2x2), 8xxxxxx = Winograd F(4x4))."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,4 +14,4 @@ m(x).sum().backward()
 plan = list(m._plans.values())[0]
 for ind, cs in sorted(plan.convs.items()):
     print('layer %2d  %4dx%-4d %4d->%-4d k%d  fwd %7d  dgrad %7d  wgrad %s' % (ind, cs.H, cs.W, cs.cin, cs.cout, cs.k, cs.plan_fwd, cs.plan_dgrad,
-                                                                              'winograd' if getattr(cs, 'wgrad_wino', False) else 'direct'))
+                                                                              ('winograd F(%dx%d)' % (cs.wgrad_wino, cs.wgrad_wino)) if getattr(cs, 'wgrad_wino', 0) else 'direct'))
