@@ -43,7 +43,7 @@ int ssp_set_option(const char* name, int value);
  *   tail 0 or 2..9 = hybrid launch: whole resident waves un-split, the last partial wave's tiles split `tail` ways);
  * a code that does not fit the shape falls back to the heuristic.  It is an argument, not state: two threads (or two
  * models) may run different plans concurrently.  The same code must be passed to the two queries.
- *   9000000 + tile_rows*100 + 10 + ring_slots (3|4|8) = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout > 64
+ *   9000000 + tile_rows*100 + 10 + ring_slots (3|4|8) = Winograd F(2x2, 3x3) evaluation of a 3x3 layer (Cin % 16 == 0, Cout >= 64
  *   and % 4 == 0; conv_wino.hip): same result to ~1e-6 of its range with 16/36 of the multiplies;
  *   8000000 + the same = Winograd F(4x4, 3x3) (points 0, 1, -1, 1/2, -2): 36/144 of the multiplies, result within ~5e-6 of its
  *   range (about twice the direct fp32 kernel's own rounding error).  `wt` must then be the TRANSFORMED filter from

@@ -129,9 +129,14 @@ def load():
     return lib
 
 
+PROF_MASK = [0]      # last mask handed to ssp_prof_enable (engine.Plan keeps its hipGraph replays off while launches are timed)
+
+
 def call(name, *args):
     """Invoke an entry point; raise SspError with the library's message on a non-zero return."""
     lib = load()
+    if name == 'ssp_prof_enable':
+        PROF_MASK[0] = int(args[0])
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.ssp_last_error()

@@ -514,8 +514,8 @@ int64_t ssp_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile) {
 static int wino_launch(ConvArgs& a, int B, int H, int W, float* ws, int64_t ws_floats, int plan, int prof_kind,
                        hipStream_t stream) {
   const int bm = (plan / 100) % 1000, slots = plan % 10, tile = ssp_wino_plan_tile(plan), P = ssp_wino_planes(tile);
-  SSP_CHECK_ARG(a.R == 3 && a.Cin % 16 == 0 && a.Cout > 64 && a.Cout % 4 == 0 && a.ldout % 4 == 0 && (((uintptr_t)a.out) & 15) == 0,
-                "conv (Winograd plan): needs a 3x3 filter, Cin %% 16 == 0, Cout > 64 and %% 4 == 0, an aligned output");
+  SSP_CHECK_ARG(a.R == 3 && a.Cin % 16 == 0 && a.Cout >= 64 && a.Cout % 4 == 0 && a.ldout % 4 == 0 && (((uintptr_t)a.out) & 15) == 0,
+                "conv (Winograd plan): needs a 3x3 filter, Cin %% 16 == 0, Cout >= 64 and %% 4 == 0, an aligned output");
   SSP_CHECK_ARG((bm == 64 || bm == 128) && (slots == 3 || slots == 4 || slots == 8) && (plan / 10) % 10 == 1 &&
                     (plan / 100000) % 10 == 0, "conv: bad Winograd plan code %d", plan);
   const int64_t T = ssp_wino_tiles(B, H, W, tile);

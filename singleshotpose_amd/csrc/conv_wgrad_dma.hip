@@ -468,6 +468,30 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   return SSP_OK;
 }
 
+// Batched launches (the P planes of a Winograd filter gradient: P x few tiles, a short pixel range each): the pixel split
+// the launcher would pick for a tile height (the smallest one filling >= 93 % of whole resident waves, launch_wgrad_dma's
+// rule; `slots` = the resident workgroups of that instantiation: 512 for 256 x 128 tiles, 768 for 128 x 128).  The 256-cout
+// tiles are the better kernel, but where they need a 3- to 5-way split (13 x 13 layers at F(4x4): 1024 rows per plane cut
+// into 13-chunk pieces, each ending in a tile of atomics) and the 128-cout tiles none or two, the latter win.
+static int wgrad_est_split(int64_t M, int batch, int Cout, int Cin, int bmo, int slots) {
+  const int64_t tiles = (int64_t)ssp_cdiv(Cout, bmo) * ssp_cdiv(Cin, 128) * (batch > 1 ? batch : 1);
+  const int64_t max_split = (M + 16 * 8 - 1) / (16 * 8);
+  int64_t lo = (slots + tiles - 1) / tiles, hi = (5 * (int64_t)slots) / tiles;
+  if (tiles >= (int64_t)(0.93 * slots)) lo = 1;
+  if (lo < 1) lo = 1;
+  if (hi < lo) hi = lo;
+  if (lo > max_split) lo = max_split;
+  if (hi > max_split) hi = max_split;
+  int64_t best_sp = lo;
+  double best = -1.0;
+  for (int64_t sp = lo; sp <= hi; ++sp) {
+    const double eff = ((double)(tiles * sp) / slots) / (double)((tiles * sp + slots - 1) / slots);
+    if (eff > best + 1e-3) { best = eff; best_sp = sp; }
+    if (eff >= 0.93) break;
+  }
+  return (int)best_sp;
+}
+
 // returns 1 when the shape is handled here (launched), 0 when the caller should use conv_wgrad.hip, < 0 on error
 int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                            int ldx, int R, hipStream_t stream, int batch, int64_t batch_dy, int64_t batch_x,
@@ -495,7 +519,8 @@ int ssp_conv_wgrad_dma_try(const float* dy, const float* x, float* dw, int B, in
   // walks per MFMA than 128x128, and - what decides it inside the training step, where the data-gradient kernel runs
   // concurrently on the other stream - two fat workgroups per CU leave that kernel room (whole-step A/B on one box:
   // 50.8 ms against 52.3 ms for 128x128 tiles at three per CU, although the stand-alone launch times are equal)
-  else if (Cout >= 256 && Cin >= 128 && wv != 8) rc = launch_wgrad_dma<256, 128, 3>(a, stream);
+  else if (Cout >= 256 && Cin >= 128 && wv != 8 && !(batch > 1 && wgrad_est_split(M, batch, Cout, Cin, 128, 768) < wgrad_est_split(M, batch, Cout, Cin, 256, 512)))
+    rc = launch_wgrad_dma<256, 128, 3>(a, stream);
   else if (Cout >= 128 && Cin >= 128 && wv == 6) rc = launch_wgrad_dma<128, 128, 3, false, true>(a, stream);   // experiment
   else if (Cout >= 128 && Cin >= 128 && wv == 3) rc = launch_wgrad_dma<128, 128, 4>(a, stream);           // experiment
   // 3-slot ring: 48 KB of LDS, three workgroups per CU (measured +3..6 % over the 4-slot ring at two per CU)

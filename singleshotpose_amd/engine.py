@@ -351,6 +351,10 @@ class Plan(object):
         self.consumed = False
         self._graph = self._graph_key = self._x_static = self._y_static = None
         self._graph_failed = False
+        self._sg_fwd = self._sg_bwd = None      # (key, graph, state) of the captured training forward / backward chains
+        self._sg_warm = 0
+        self._sg_failed = False
+        self._sg_fwd_live = False
 
     def footprint(self):
         """Bytes of device memory this plan's forward buffers hold or will hold after a training-mode forward (each storage
@@ -659,11 +663,10 @@ class Plan(object):
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
                     cs.cin % 16 == 0 and cs.cout % 16 == 0):
                 return ()
-            n_out = cs.cout if which == 'fwd' else cs.cin      # the batched GEMM kernel wants more than 64 output columns
             bases = []
-            if 2 in wino_tiles and min(cs.cin, cs.cout) >= wino_min and n_out > 64:
+            if 2 in wino_tiles and min(cs.cin, cs.cout) >= wino_min:
                 bases.append(WINO)
-            if 4 in wino_tiles and min(cs.cin, cs.cout) >= 64 and n_out > 64:
+            if 4 in wino_tiles and min(cs.cin, cs.cout) >= 64:
                 bases.append(WINO4)
             return tuple(bases)
 
@@ -695,7 +698,7 @@ class Plan(object):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(1234)
 
-        def best_of(launch, mn, key, extra=()):
+        def best_of(launch, mn, key, extra=(), direct=None):
             keep = True
             if key in _TUNE_CACHE:       # the same launch shape was timed before (another plan, another model)
                 if not wino_tile(_TUNE_CACHE[key]) or _TUNE_CACHE[key] in extra:
@@ -707,7 +710,9 @@ class Plan(object):
             # deep K splits put every CU on the weight stream
             deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4, 8)) \
                 if mn <= (1 << 21) else ()
-            for code in cands + (lat if mn <= (1 << 23) else ()) + deep + tuple(extra):
+            # (direct: the direct-plan candidates of this launch when the standard list does not apply - a thin data
+            # gradient, Cin_dx <= 64, ignores plan codes: its heuristic plan alone is timed against the Winograd forms)
+            for code in (tuple(direct) if direct is not None else cands + (lat if mn <= (1 << 23) else ()) + deep) + tuple(extra):
                 if not wino_tile(code) and ((code // 10) % 10 > 1 or code >= 100000) and mn > (1 << 25):
                     continue      # no split-K scratch for the biggest maps (dozens of waves: nothing to balance)
                 try:
@@ -805,7 +810,7 @@ class Plan(object):
                                        (lambda code=code: prep_f(wino_tile(code))) if wino_tile(code) else None)
                 # not chosen: the transformed-filter buffers go back to the allocator
                 cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
-            if which == 'dgrad' and not cs.first and cs.cin > 64 and cs.coutp % 16 == 0:
+            if which == 'dgrad' and not cs.first and cs.coutp % 16 == 0 and (cs.cin > 64 or wino_codes(cs, which)):
                 key = self._dgrad_key(cs)
                 wslice = self._dpack[cs.doff:cs.doff + cs.cinp * cs.k * cs.k * cs.coutp]
 
@@ -823,7 +828,7 @@ class Plan(object):
                 if wc and key not in _TUNE_CACHE:
                     for t in sorted(set(wino_tile(c) for c in wc)):
                         prep_d(t)
-                code = best_of(launch, cs.M * cs.cinp, key, wc)
+                code = best_of(launch, cs.M * cs.cinp, key, wc, direct=None if cs.cin > 64 else (0,))
                 cs.plan_dgrad = admitted(code, key, launch, lambda cs=cs: gscratch[:cs.M * cs.inp.ld],
                                          [(cs.raw, cs.ldraw, 0, cs.cout), wslice], None,
                                          (lambda code=code: prep_d(wino_tile(code))) if wino_tile(code) else None)
@@ -841,6 +846,80 @@ class Plan(object):
             call('ssp_u8hwc_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, H, W, self.in_c, self.in_cp, self.in_cp, st)
         else:
             call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
+        # Everything between the two layout conversions is a fixed chain of launches on plan-owned buffers: small training
+        # steps (the cfg's own batch 8: ~300 launches of a few microseconds each, host-bound) replay it from a hipGraph
+        self._sg_fwd_live = False
+        if self._step_graph_mode(training, need_grad, inline_repack):
+            key = self._sg_key()
+            if self._sg_fwd is not None and self._sg_fwd[0] == key:
+                self._sg_fwd[1].replay()
+                self._sg_restore(self._sg_fwd[2])
+                self._sg_fwd_live = True
+            elif self._sg_warm >= 2:
+                try:
+                    g = self._sg_capture(lambda: self._forward_body(training, need_grad, False, join_side=True))
+                    self._sg_fwd = (key, g, self._sg_state())
+                    g.replay()
+                    self._sg_fwd_live = True
+                except Exception as e:      # capture unsupported here: keep the eager launches
+                    self._sg_fail(e)
+                    self._forward_body(training, need_grad, inline_repack)
+            else:
+                self._sg_warm += 1
+                self._forward_body(training, need_grad, inline_repack)
+        else:
+            self._forward_body(training, need_grad, inline_repack)
+        o = self.out_act
+        y = torch.empty(B, o.C, o.H, o.W, dtype=torch.float32, device=self.device)
+        call('ssp_nhwc_to_nchw', o.ptr, y.data_ptr(), B, o.C, o.H, o.W, o.ld, st)
+        self.consumed = False
+        self.was_training = training
+        self.generation += 1
+        return y
+
+    # ------------------------------------------------------------------ training step as two hipGraphs
+    def _step_graph_mode(self, training, need_grad, inline_repack):
+        """SSP_STEP_GRAPH=0 / 1 / auto (default: plans of at most 2^21 input pixels - batch 8 at 416 x 416, not the metric's
+        batch 64, which is GPU-bound and keeps its HIP-event timers).  Never with a gradient reducer attached (collectives
+        stay eager) or while the launch timer is on (its events belong to individual launches)."""
+        if not (training and need_grad) or inline_repack or self.reducer is not None or self._sg_failed:
+            return False
+        mode = os.environ.get('SSP_STEP_GRAPH', 'auto')
+        if mode == '0' or _lib.PROF_MASK[0] != 0:
+            return False
+        return mode == '1' or self.B * self.H * self.W <= (1 << 21)
+
+    def _sg_key(self):
+        return tuple((t.data_ptr(), tuple(t.stride())) for t in self._graph_tensors())
+
+    def _sg_capture(self, fn):
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            fn()
+        return g
+
+    def _sg_fail(self, e):
+        import warnings
+        warnings.warn("hipGraph capture of the training step failed (%s); using eager launches" % (e,))
+        self._sg_failed = True
+        self._sg_fwd = self._sg_bwd = None
+        torch.cuda.synchronize(self.device)
+
+    def _sg_state(self):
+        """Host-side flags a forward body leaves behind (restored after a replay)."""
+        return [(cs, cs.first_live, getattr(cs, 'v_live', False), cs.packed) for cs in self.convs.values()]
+
+    def _sg_restore(self, state):
+        for cs, first_live, v_live, packed in state:
+            cs.first_live, cs.v_live, cs.packed = first_live, v_live, packed
+        self.net._bn_epoch += 1
+        self.dgrad_ready = True      # the captured chain joined the side stream: the data-gradient operands are in place
+
+    def _forward_body(self, training, need_grad, inline_repack, join_side=False):
+        B, H, W = self.B, self.H, self.W
+        st = torch.cuda.current_stream().cuda_stream
+        call = _lib.call
         # Filter repacks depend only on the weights, not on the activations: they run on the side stream, ahead of the
         # convolutions that use them, instead of as one more dependent launch
         # in front of every conv on the main stream.  Forward operands first (two events: the first four layers, then
@@ -1003,13 +1082,11 @@ class Plan(object):
                 for s in srcs:
                     call('ssp_copy_channels', s.ptr, s.ld, _ptr(out.t, off), out.ld, s.C, B * s.H * s.W, 0, st)
                     off += s.C
-        o = self.out_act
-        y = torch.empty(B, o.C, o.H, o.W, dtype=torch.float32, device=self.device)
-        call('ssp_nhwc_to_nchw', o.ptr, y.data_ptr(), B, o.C, o.H, o.W, o.ld, st)
-        self.consumed = False
-        self.was_training = training
-        self.generation += 1
-        return y
+        if join_side and self.side_stream is not None:
+            # captured chain: every forked stream rejoins (the data-gradient operand repacks included)
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            if self.dgrad_ready is not None:
+                self.dgrad_ready = True
 
     # ------------------------------------------------------------------ inference as one hipGraph
     def _graph_tensors(self):
@@ -1069,26 +1146,67 @@ class Plan(object):
         B = self.B
         st = torch.cuda.current_stream().cuda_stream
         call = _lib.call
-        blocks = self.net.blocks
         o = self.out_act
-        written = set()
-        fused_stats = set()      # blocks whose BatchNorm-backward reductions were produced by their consumer's dgrad launch
         g_last = self._grad_buf(self.last, o)
         call('ssp_nchw_to_nhwc', grad_out.data_ptr(), g_last.ptr, B, o.C, o.H, o.W, o.C, o.ld, st)
         if o.ld > o.C:
             raise NotImplementedError("network output channels must be a multiple of 4")
+        if self.side_stream is None:
+            self.side_stream = _side_stream(self.device)
+        # ONE flat gradient buffer per model and device, reused by every backward of every plan (the layout depends on the
+        # model only): the returned gradients are views of it.  Reuse is safe only while nothing else still views the
+        # buffer (optimizer.zero_grad(set_to_none=True) - torch's default - drops the .grad views; a caller that keeps or
+        # accumulates gradients across backwards gets a fresh buffer, the old one stays with the tensors that view it).
+        # Zeroed (in the body): the filter-gradient kernel accumulates channels-last parameters' gradients straight into it.
+        ent = self.net._flat_grads.get(self.device)
+        flat = None
+        if ent is not None and ent[0].numel() == self.grad_total and not _storage_shared(ent[0], ent[1], self.net._params()):
+            flat = ent[0]
+        if flat is None:
+            flat = torch.empty(self.grad_total, dtype=torch.float32, device=self.device)
+            self.net._flat_grads[self.device] = (flat, _storage_refs(flat))
+        flat.record_stream(self.side_stream)
+        self.last_flat_grad = flat
+        # the backward chain of a forward that was replayed from its hipGraph is a fixed launch sequence too
+        if self._sg_fwd_live and not self.serial_backward and self._step_graph_mode(self.was_training, True, False):
+            key = (self._sg_key(), flat.data_ptr())
+            if self._sg_bwd is not None and self._sg_bwd[0] == key:
+                self._sg_bwd[1].replay()
+                for cs in self.convs.values():
+                    cs.v_live = False
+                return {pid: torch.as_strided(flat, shape, stride, off) for pid, shape, stride, off in self._sg_bwd[2]}
+            try:
+                box = {}
+                g = self._sg_capture(lambda: box.update(out=self._backward_body(flat)))
+                out_grads = box['out']
+                self._sg_bwd = (key, g, [(pid, tuple(t.shape), tuple(t.stride()), t.storage_offset())
+                                         for pid, t in out_grads.items()])
+                g.replay()
+                return out_grads
+            except Exception as e:
+                self._sg_fail(e)
+        return self._backward_body(flat)
+
+    def _backward_body(self, flat):
+        B = self.B
+        st = torch.cuda.current_stream().cuda_stream
+        call = _lib.call
+        blocks = self.net.blocks
+        written = set()
+        fused_stats = set()      # blocks whose BatchNorm-backward reductions were produced by their consumer's dgrad launch
         written.add(self.last)
+        flat.zero_()
         for cs in self.convs.values():          # gradient staging of the parameters that are not channels-last
             if not cs.packed:
                 self._gbuf(cs).zero_()
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
-        if self.side_stream is None:
-            self.side_stream = _side_stream(self.device)
         main = torch.cuda.current_stream()
         side = main if self.serial_backward else self.side_stream
         st2 = side.cuda_stream
-        if self.dgrad_ready is not None:
+        if self.dgrad_ready is True:
+            pass                                    # the forward chain (a hipGraph) already joined the operand repacks
+        elif self.dgrad_ready is not None:
             main.wait_event(self.dgrad_ready)       # dgrad filter repacks were queued during forward
         else:
             self._prepare_backward(tune=False)      # the saved conv outputs are live: no timing / verify launches now
@@ -1098,21 +1216,6 @@ class Plan(object):
                     self._repack_dgrad(cs, main)
         out_grads = {}
         training = self.was_training
-        # ONE flat gradient buffer per model and device, reused by every backward of every plan (the layout depends on the
-        # model only): the returned gradients are views of it.  Reuse is safe only while nothing else still views the
-        # buffer (optimizer.zero_grad(set_to_none=True) - torch's default - drops the .grad views; a caller that keeps or
-        # accumulates gradients across backwards gets a fresh buffer, the old one stays with the tensors that view it).
-        # Zeroed: the filter-gradient kernel accumulates channels-last parameters' gradients straight into it.
-        ent = self.net._flat_grads.get(self.device)
-        flat = None
-        if ent is not None and ent[0].numel() == self.grad_total and not _storage_shared(ent[0], ent[1], self.net._params()):
-            flat = ent[0]
-            flat.zero_()
-        if flat is None:
-            flat = torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)
-            self.net._flat_grads[self.device] = (flat, _storage_refs(flat))
-        flat.record_stream(side)
-        self.last_flat_grad = flat
         if self.reducer is not None:
             self.reducer.begin(flat)
 

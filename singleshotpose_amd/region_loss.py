@@ -65,9 +65,8 @@ class _RegionLossFn(torch.autograd.Function):
                   float(mod.thresh), conf_on, 1 if mod._multi else 0,
                   anchors.data_ptr() if anchors is not None else None, step, st)
         for slot in mod.__dict__.get('_pin_ring', {}).values():
-            rel = slot.pop('release', None)
-            if rel is not None:
-                rel[0].record(rel[1])       # this slot's pinned and device label buffers are free once the kernel has run
+            for ev, stream in slot.pop('release', ()):
+                ev.record(stream)           # this slot's pinned and device label buffers are free once the kernel has run
         ctx.save_for_backward(grad)
         mod._last_stats = stats
         return stats[4].clone()
@@ -146,7 +145,12 @@ class _RegionLossBase(nn.Module):
             out = slot['dev'][i]
         if not getattr(self, '_probe_no_events', False):      # (tools/label_upload_probe.py's diagnostic mode drops the events)
             slot['used'][i] = True
-            slot['release'] = (slot['events'][i], stream)      # recorded by forward() after the kernel that reads the labels
+            # recorded now - behind the copy that reads the pinned buffer - and AGAIN by forward() behind the kernel that
+            # reads the device twin (a re-record moves the event later).  Recording here as well keeps the slot's event valid
+            # when no kernel follows this upload (an exception between the two, a second upload of the same shape): the
+            # reuse wait four calls later then still orders itself after the copy instead of returning on a stale event.
+            slot['events'][i].record(stream)
+            slot.setdefault('release', []).append((slot['events'][i], stream))
         t3 = time.perf_counter()
         hist = self.__dict__.setdefault('upload_host_us', [])
         hist.append(((t3 - t0) * 1e6, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6))   # total, ring wait, host copy, H2D issue

@@ -85,7 +85,7 @@ def run_cases(args, dev, st, B):
         for plan in [int(v) for v in args.plans.split(',')]:
             tile = _lib.query('ssp_conv_plan_wino_tile', plan)      # 2 / 4: Winograd F(2x2) / F(4x4) plan, 0: direct
             wino = tile > 0
-            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout <= 64 or Cin < 64):
+            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout < 64 or Cin < 64):
                 continue
             wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, plan), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, plan))
             ws = torch.empty(wsn, device=dev)
@@ -112,7 +112,7 @@ def run_cases(args, dev, st, B):
                 wsw = torch.empty(_lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile), device=dev)
             line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d plan %7d |' % (name, H, Cin, Cout, R, plan)
             for op in args.ops.split(','):
-                if (op == 'dgrad' and (name == 'l0' or (wino and Cin <= 64))) or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
+                if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
                     continue
                 fn = fns[op]
                 for _ in range(3):

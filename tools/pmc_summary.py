@@ -18,3 +18,9 @@ for k, d in sorted(agg.items()):
         if wc and c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_SCA'):
             extra = '  %.1f%% of wave cycles' % (100.0 * m / wc)
         print('   %-28s %16.0f (n=%d)%s' % (c, m, len(v), extra))
+    # derived (profiles/README.md): counters are summed over the 8 XCDs; MFMA pipe utilisation = busy cycles / (cycles x 1024 SIMDs)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d:
+        busy = sum(d['SQ_VALU_MFMA_BUSY_CYCLES']) / len(d['SQ_VALU_MFMA_BUSY_CYCLES'])
+        act = sum(d['GRBM_GUI_ACTIVE']) / len(d['GRBM_GUI_ACTIVE'])
+        print('   %-28s %15.1f%%' % ('-> MFMA pipe busy', 100.0 * busy / (act / 8.0 * 1024.0)))
+
