@@ -21,6 +21,12 @@ import re
 import sys
 import time
 
+# HIP multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default).  RCCL brings its own streams:
+# with 4 queues the step's two compute streams then share one and run one after the other (measured on one rank with a live
+# process group, profiles/r04_rccl_queues.txt: 35.7 ms per step against 28.4 ms; 28.9 ms with 8 queues).  Read when the HIP
+# runtime initialises, so it is set before torch is imported; an explicit setting in the environment wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -449,7 +455,7 @@ def main():
         torch.cuda.synchronize()
 
     grad_check = None
-    if dist_on:
+    if dist_on and os.environ.get('SSP_BENCH_SKIP_GRAD_CHECK') != '1':
         # SURVEY.md 8(d) config 3, untimed: every rank runs the SAME batch (same seed, same initial weights), once with the
         # reducer standing aside and once through it - the reduced flat gradient must be world x the local one (<= 1e-5 of
         # its range; the filter-gradient kernels' fp32 atomics make two evaluations differ in the last bits)

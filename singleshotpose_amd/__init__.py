@@ -3,6 +3,15 @@
 Host side mirrors the reference's Python surface (cfg.py, darknet.py, region_loss.py, utils.py); all device work is
 hand-written HIP behind the C ABI in include/ssp_hip.h (libssp_hip.so).  See DESIGN.md.
 """
+import os as _os
+
+# HIP hands a process's streams to GPU_MAX_HW_QUEUES hardware queues (default 4); with RCCL's own streams in the process the
+# engine's two compute streams then share one queue and lose their overlap (bench.py has the numbers: 35.7 ms per step
+# against 28.9 ms with 8 queues).  The runtime reads the variable when it initialises - this default only helps a process
+# that imports the package before its first HIP call; multi-GPU launch scripts should export it themselves
+# (INTEGRATION.md section 4).  An explicit setting wins.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from . import _lib  # noqa: F401
 from .cfg import parse_cfg, print_cfg  # noqa: F401
 from .darknet import Darknet  # noqa: F401

@@ -26,6 +26,11 @@ def init_distributed(backend=None):
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # "nccl" is RCCL on ROCm
+    if backend == 'nccl' and torch.cuda.is_available():
+        # the engine's second compute stream first: HIP hands its streams to a few hardware queues in creation order, and
+        # behind RCCL's own streams it would share the main stream's queue (engine._side_stream)
+        from .engine import _side_stream
+        _side_stream(torch.device('cuda', torch.cuda.current_device()))
     dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')),
                             world_size=int(os.environ.get('WORLD_SIZE', '1')))
 

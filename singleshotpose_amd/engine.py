@@ -91,12 +91,25 @@ def _storage_shared(t, refs_alone, params):
     return any(p.grad is not None and p.grad.untyped_storage().data_ptr() == sp for p in params)
 
 
+_SIDE_STREAMS = {}
+
+
 def _side_stream(device):
     """The second stream (filter repacks / transforms in forward, filter gradients in backward), at the HIGH HIP stream
     priority: its launches then win the dispatch slots that free up next to the main stream's, which shortened the step by
     0.2-0.3 ms (0.6 %) in two interleaved A/B rounds (profiles/r03_step_ab_winograd.txt).  SSP_SIDE_PRIORITY=0 restores the
-    runtime's default (the device offers 0 and -1)."""
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get('SSP_SIDE_PRIORITY', '-1')))
+    runtime's default (the device offers 0 and -1).
+
+    ONE per device and process, shared by every plan, and created as early as possible (dist.init_distributed creates it
+    BEFORE the RCCL process group): HIP multiplexes its streams over a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    default) in creation order, and a side stream created after RCCL's own streams landed on the main stream's queue -
+    the two chains then ran one after the other instead of side by side (single-rank rehearsal, profiles/r04_rccl_queues.txt:
+    forward 12.1 ms with no two kernels ever overlapping against 10.1 ms, step 35.7 ms against 28.7 ms)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('SSP_SIDE_PRIORITY', '-1')))
+    return st
 
 
 def weights_changed():
@@ -355,6 +368,7 @@ class Plan(object):
         self._sg_warm = 0
         self._sg_failed = False
         self._sg_fwd_live = False
+        self._sg_serial = False      # SSP_STEP_GRAPH=2: the captured chains run on one stream
 
     def footprint(self):
         """Bytes of device memory this plan's forward buffers hold or will hold after a training-mode forward (each storage
@@ -879,15 +893,18 @@ class Plan(object):
 
     # ------------------------------------------------------------------ training step as two hipGraphs
     def _step_graph_mode(self, training, need_grad, inline_repack):
-        """SSP_STEP_GRAPH=0 / 1 / auto (default: plans of at most 2^21 input pixels - batch 8 at 416 x 416, not the metric's
-        batch 64, which is GPU-bound and keeps its HIP-event timers).  Never with a gradient reducer attached (collectives
-        stay eager) or while the launch timer is on (its events belong to individual launches)."""
+        """SSP_STEP_GRAPH=1: two-stream chains as captured, =2: the same launches captured on ONE stream (a linear graph);
+        default 0 = eager launches - measured on this runtime (profiles/r04_step_graph.txt): a replayed two-stream chain of
+        ~300 nodes is SLOWER than launching it (batch 8: 9.1 ms against 6.0 ms eager), so nothing takes this path unasked.
+        Never with a gradient reducer attached (collectives stay eager) or while the launch timer is on (its events belong
+        to individual launches)."""
         if not (training and need_grad) or inline_repack or self.reducer is not None or self._sg_failed:
             return False
-        mode = os.environ.get('SSP_STEP_GRAPH', 'auto')
-        if mode == '0' or _lib.PROF_MASK[0] != 0:
+        mode = os.environ.get('SSP_STEP_GRAPH', '0')
+        if mode not in ('1', '2') or _lib.PROF_MASK[0] != 0:
             return False
-        return mode == '1' or self.B * self.H * self.W <= (1 << 21)
+        self._sg_serial = mode == '2'
+        return True
 
     def _sg_key(self):
         return tuple((t.data_ptr(), tuple(t.stride())) for t in self._graph_tensors())
@@ -966,7 +983,8 @@ class Plan(object):
         if stale or need_grad or wino:
             if self.side_stream is None:
                 self.side_stream = _side_stream(self.device)
-            side = self.side_stream
+            # (SSP_STEP_GRAPH=2, capturing: everything on the capturing stream - a linear chain)
+            side = torch.cuda.current_stream() if (join_side and self._sg_serial) else self.side_stream
             side.wait_stream(torch.cuda.current_stream())
             for group in (stale[:4], stale[4:]):
                 for cs, key in group:
@@ -1084,7 +1102,8 @@ class Plan(object):
                     off += s.C
         if join_side and self.side_stream is not None:
             # captured chain: every forked stream rejoins (the data-gradient operand repacks included)
-            torch.cuda.current_stream().wait_stream(self.side_stream)
+            if not self._sg_serial:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
             if self.dgrad_ready is not None:
                 self.dgrad_ready = True
 
@@ -1202,7 +1221,7 @@ class Plan(object):
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
         main = torch.cuda.current_stream()
-        side = main if self.serial_backward else self.side_stream
+        side = main if (self.serial_backward or (self._sg_serial and self._sg_fwd_live)) else self.side_stream
         st2 = side.cuda_stream
         if self.dgrad_ready is True:
             pass                                    # the forward chain (a hipGraph) already joined the operand repacks
