@@ -92,7 +92,8 @@ static WinoGeom wino_geom(int B, int H, int W, int tile) {
 }
 
 // ---- V = B^T d B: thread = (tile, CV channels) -------------------------------------------------------------------------
-template <int N, int CV>
+// NT: non-temporal stores for the planes (written once here, read once by the GEMM launch)
+template <int N, int CV, bool NT = false>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ in, int ldin, float* __restrict__ V, int C,
                                                          WinoGeom g, SspFastDiv div_cg) {
   constexpr int A = N + 2;
@@ -152,7 +153,8 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
         constexpr int k = decltype(K)::value;
         { constexpr float cc_ = M_::BT[j][k]; wino_mad(a, cc_, r[i][k]); }
       });
-      *reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane) = a;
+      if constexpr (NT) __builtin_nontemporal_store(a, reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane));
+      else *reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane) = a;
     });
   });
 }
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
 // an n x n tile of the output gradient spread over the transform domain) and V the transformed input of the forward pass;
 // then dL/dg = G^T (dL/dU) G.  The P sums over the tiles are P pixel-contraction GEMMs - one batched launch of the
 // LDS-direct filter-gradient kernel (conv_wgrad_dma.hip, R = 1, gridDim.y = P).
-template <int N, int CV>
+template <int N, int CV, bool NT = false>
 __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dM, int C,
                                                            WinoGeom g, SspFastDiv div_cg) {
   constexpr int A = N + 2;
@@ -419,7 +421,8 @@ __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restri
         constexpr int qq = decltype(Q)::value;
         { constexpr float cc_ = M_::AT[qq][j]; wino_mad(a, cc_, r[i][qq]); }
       });
-      *reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane) = a;
+      if constexpr (NT) __builtin_nontemporal_store(a, reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane));
+      else *reinterpret_cast<vec*>(dst + (int64_t)(i * A + j) * plane) = a;
     });
   });
 }
@@ -480,7 +483,8 @@ int64_t ssp_wino_stat_groups(int B, int H, int W, int tile) { return (ssp_wino_t
 int ssp_wino_outgrad_launch(const float* dy, int lddy, float* dM, int B, int H, int W, int C, int tile, hipStream_t stream) {
   SSP_CHECK_ARG(wino_tile_ok(tile), "wino_outgrad: tile must be 2 or 4");
   const WinoGeom g = wino_geom(B, H, W, tile);
-  const int cv = tile == 2 ? 4 : 2;
+  const int wv = ssp_option(SSP_OPT_WINO_VARIANT);      // experiments: bit 0 = 4 channels per thread at F(4x4), bit 1 = non-temporal stores
+  const int cv = (tile == 2 || (wv & 1)) ? 4 : 2;
   SSP_CHECK_ARG(C % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)dM) & 15) == 0,
                 "wino_outgrad: channels must be a multiple of 4 and the operands 16-byte aligned");
   SSP_CHECK_ARG(g.T * (C / cv) < (1ll << 31), "wino_outgrad: too many (tile, channel) pairs");
@@ -488,8 +492,13 @@ int ssp_wino_outgrad_launch(const float* dy, int lddy, float* dM, int B, int H, 
   SspProfScope prof(SSP_PROF_WINO_WGRAD, stream, 4.0 * C * ((double)B * H * W + (double)P * g.T));
   const int64_t n = g.T * (C / cv);
   const SspFastDiv dc = ssp_fastdiv((unsigned)(C / cv));
-  if (tile == 2) hipLaunchKernelGGL((wino_outgrad_kernel<2, 4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
-  else hipLaunchKernelGGL((wino_outgrad_kernel<4, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (tile == 2 && (wv & 2)) hipLaunchKernelGGL((wino_outgrad_kernel<2, 4, true>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  else if (tile == 2) hipLaunchKernelGGL((wino_outgrad_kernel<2, 4>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  else if (cv == 4 && (wv & 2)) hipLaunchKernelGGL((wino_outgrad_kernel<4, 4, true>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  else if (cv == 4) hipLaunchKernelGGL((wino_outgrad_kernel<4, 4>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  else if (wv & 2) hipLaunchKernelGGL((wino_outgrad_kernel<4, 2, true>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
+  else hipLaunchKernelGGL((wino_outgrad_kernel<4, 2>), grid, dim3(256), 0, stream, dy, lddy, dM, C, g, dc);
   SSP_CHECK_LAUNCH("wino_outgrad");
   return SSP_OK;
 }
@@ -507,7 +516,8 @@ int ssp_wino_wgrad_finish_launch(const float* dU, float* dw, int rows, int K, in
 int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int W, int C, int tile, int prof_kind, hipStream_t stream) {
   SSP_CHECK_ARG(wino_tile_ok(tile), "wino_input: tile must be 2 or 4");
   const WinoGeom g = wino_geom(B, H, W, tile);
-  const int cv = tile == 2 ? 4 : 2;
+  const int wv = ssp_option(SSP_OPT_WINO_VARIANT);
+  const int cv = (tile == 2 || (wv & 1)) ? 4 : 2;
   SSP_CHECK_ARG(C % 4 == 0 && ldin % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)V) & 15) == 0,
                 "wino_input: channels must be a multiple of 4 and the operands 16-byte aligned");
   SSP_CHECK_ARG(g.T * (C / cv) < (1ll << 31), "wino_input: too many (tile, channel) pairs");
@@ -515,8 +525,13 @@ int ssp_wino_input_launch(const float* in, int ldin, float* V, int B, int H, int
   SspProfScope prof(prof_kind, stream, 4.0 * C * ((double)B * H * W + (double)P * g.T));
   const int64_t n = g.T * (C / cv);
   const SspFastDiv dc = ssp_fastdiv((unsigned)(C / cv));
-  if (tile == 2) hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, ldin, V, C, g, dc);
-  else hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (tile == 2 && (wv & 2)) hipLaunchKernelGGL((wino_input_kernel<2, 4, true>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  else if (tile == 2) hipLaunchKernelGGL((wino_input_kernel<2, 4>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  else if (cv == 4 && (wv & 2)) hipLaunchKernelGGL((wino_input_kernel<4, 4, true>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  else if (cv == 4) hipLaunchKernelGGL((wino_input_kernel<4, 4>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  else if (wv & 2) hipLaunchKernelGGL((wino_input_kernel<4, 2, true>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
+  else hipLaunchKernelGGL((wino_input_kernel<4, 2>), grid, dim3(256), 0, stream, in, ldin, V, C, g, dc);
   SSP_CHECK_LAUNCH("wino_input");
   return SSP_OK;
 }
