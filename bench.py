@@ -7,12 +7,15 @@ synthetic 416x416 batches, 64 images per GPU (BASELINE.json metric).
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` = images/s of the whole job (all ranks), max-over-ranks time of exactly K
-steps between barrier + synchronize pairs, inputs resident in HBM.  `roofline` is for the dominant kernel
-(the implicit-GEMM conv kernel): algorithmic conv FLOPs of its forward launches / their HIP-event time, against the
-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), from HIP events around exactly those launches inside the timed
-region; the backward conv launches overlap on two streams and are reported together in `roofline_bwd`, which - like
-`kernel_ms_per_step` - comes from a second, untimed pass with every launch bracketed by events.  `cpu_baseline` times the CPU oracle of the same step
-(oracle/: the reference's PyTorch-CPU semantics) on this host for a bounded batch - rank 0, N=1 only.
+steps between barrier + synchronize pairs, inputs resident in HBM.  `roofline` is for the dominant kernel (the
+implicit-GEMM conv kernel, forward launches): the FLOPs its MFMA pipe EXECUTED (a Winograd-plan layer counts its batched
+GEMMs, not the direct convolution) / the HIP-event time of those launches, against the fp32 MFMA peak (157.3 TFLOP/s,
+MI355X_MICROARCH.md), from HIP events inside the timed region; `launch_units` in it charges the HBM-bound Winograd
+transform / finishing launches to the same FLOPs, `effective` is the algorithmic (direct-convolution) rate.
+`roofline_wino_transforms` is the HBM roofline of those passes.  `roofline_dgrad` / `roofline_wgrad` (kernel-exclusive) and
+`roofline_bwd` (the two backward streams as they overlap in the step) come - like `kernel_ms_per_step` - from further,
+untimed passes with the launches bracketed by events.  `cpu_baseline` times the reference's own modules (or the CPU
+oracle of the same step, oracle/) on this host for a bounded batch - rank 0, N=1 only.
 """
 import argparse
 import json
@@ -502,7 +505,9 @@ def main():
     # Timed region: HIP events only around the FORWARD launches of the dominant kernel (what `roofline` needs; every
     # timed launch adds two event packets to its stream: all ~240 launches of a step timed cost 0.9 ms, these 23 cost
     # <0.1 ms).  --timers all / none change that.
-    _lib.call('ssp_prof_enable', {'conv': 0b001, 'all': -1, 'none': 0}[args.timers])
+    # (bit 0 = the forward conv launch units, bit 9 = the Winograd transform / finishing launches inside them: the dominant
+    # kernel's own time is the difference)
+    _lib.call('ssp_prof_enable', {'conv': (1 << 0) | (1 << 9), 'all': -1, 'none': 0}[args.timers])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -570,9 +575,9 @@ def main():
                            "work_per_step": bwork[k] / nb} for k in range(nk)}
         # Dominant kernel family = the implicit-GEMM conv kernel.  Its FORWARD launches run alone on the GPU, so their
         # HIP-event durations are kernel-exclusive and are taken INSIDE the timed region.
-        ig_ms, ig_flop, ig_n, ig_steps = ms[0], work[0], cnt[0], args.steps
+        ig_ms, ig_flop, ig_n, ig_steps, ig_wino = ms[0], work[0], cnt[0], args.steps, ms[9]
         if ig_ms <= 0:      # --timers none: take the forward launches of the breakdown pass
-            ig_ms, ig_flop, ig_n, ig_steps = bms[0], bwork[0], bcnt[0], nb
+            ig_ms, ig_flop, ig_n, ig_steps, ig_wino = bms[0], bwork[0], bcnt[0], nb, bms[9]
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         bwd_ms = max(bms[1], bms[2])   # the two streams run concurrently: wall time of the conv backward ~ the longer one
         bwd_tf = (bwork[1] + bwork[2]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
@@ -607,28 +612,30 @@ def main():
                  "workload: <64, 128, %d, 3|4, 2, 2> (batched Winograd GEMMs and mid-size grids), <128, 128, %d, 3, 2, 2>, "
                  "<128, 64, %d, 3, 2, 2> (Cout <= 64), <256, 32, %d, 4, 4, 1> (Cout <= 32)")
 
-        def family(fam, kernel, ms_, n_, note, wino_ms=None):
-            """MFMA roofline object of one conv family: executed FLOPs / HIP-event time of its launch units (a Winograd
-            layer's transform, batched GEMM and finishing launches are one unit)."""
-            tf = exe[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+        def family(fam, kernel, ms_, n_, note, wino_ms):
+            """MFMA roofline object of one conv family.  The DOMINANT KERNEL is the implicit-GEMM / filter-gradient MFMA
+            kernel itself: achieved = EXECUTED FLOPs / the HIP-event time of its launches (= the launch units' time minus the
+            HBM-bound Winograd transform / finishing launches inside them, which have their own roofline object).  The same
+            FLOPs over the whole units - transforms included - are `launch_units`."""
+            gemm_ms = ms_ - (wino_ms or 0.0)
+            tf = exe[fam] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            utf = exe[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
             eff = alg[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
-            o = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                 "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                 "flop_per_step": exe[fam], "ms_per_step": round(ms_, 3), "launches_per_step": n_,
-                 "avg_launch_ms": round(ms_ / max(n_, 1), 4),
-                 "effective": {"tflops": round(eff, 2), "frac_of_peak": round(eff / PEAK_FP32_MFMA_TFLOPS, 4),
-                               "flop_per_step": alg[fam],
-                               "note": "ALGORITHMIC (direct-convolution) FLOPs / the same time: not a roofline fraction - "
-                                       "Winograd layers need fewer multiplies than it counts"},
-                 "winograd_layers": {"F(2x2,3x3)": wino_layers[fam][2], "F(4x4,3x3)": wino_layers[fam][4]},
-                 "note": note}
-            if wino_ms is not None and ms_ > wino_ms > 0:
-                g = exe[fam] / ((ms_ - wino_ms) * 1e-3) / 1e12
-                o["gemm_kernels_only"] = {"achieved": round(g, 2), "frac": round(g / PEAK_FP32_MFMA_TFLOPS, 4),
-                                          "ms_per_step": round(ms_ - wino_ms, 3),
-                                          "note": "the same FLOPs / (unit time - the HBM-bound Winograd transform and finishing "
-                                                  "launches inside the units, timed in an untimed pass): the MFMA kernels alone"}
-            return o
+            return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "flop_per_step": exe[fam], "ms_per_step": round(gemm_ms, 3), "launches_per_step": n_,
+                    "avg_launch_ms": round(gemm_ms / max(n_, 1), 4),
+                    "launch_units": {"achieved": round(utf, 2), "frac": round(utf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                     "ms_per_step": round(ms_, 3),
+                                     "note": "the same executed FLOPs / the time of the whole launch units: a Winograd layer's "
+                                             "input transform, batched GEMM and finishing launches together (the HBM-bound "
+                                             "passes charged to the matrix pipe)"},
+                    "effective": {"tflops": round(eff, 2), "frac_of_peak": round(eff / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  "flop_per_step": alg[fam],
+                                  "note": "ALGORITHMIC (direct-convolution) FLOPs / the launch units' time: not a roofline "
+                                          "fraction - Winograd layers need fewer multiplies than it counts"},
+                    "winograd_layers": {"F(2x2,3x3)": wino_layers[fam][2], "F(4x4,3x3)": wino_layers[fam][4]},
+                    "note": note}
 
         def hbm_family(fam, ms_, bytes_, n_):
             """HBM roofline object of the Winograd transform / finishing passes of one conv family."""
@@ -637,9 +644,10 @@ def main():
                     "bytes_per_step": bytes_, "launches_per_step": n_}
 
         wk = {'fwd': 9, 'dgrad': 10, 'wgrad': 11}
-        wino_fwd_ms = bms[9] / nb if nb else 0.0
         wino_traffic, wino_traffic_src = wino_traffic_per_step()
-        hb = [hbm_family('fwd', bms[9] / nb, bwork[9] / nb, bcnt[9] / nb), hbm_family('dgrad', *ex[10]),
+        # (forward passes: from the timed region itself when its timers are on, else from the untimed all-timers pass)
+        fw = (ms[9] / args.steps, work[9] / args.steps, cnt[9] / args.steps) if ms[0] > 0 else (bms[9] / nb, bwork[9] / nb, bcnt[9] / nb)
+        hb = [hbm_family('fwd', *fw), hbm_family('dgrad', *ex[10]),
               hbm_family('wgrad', *ex[11])]
         hb_ms = sum(h["ms_per_step"] for h in hb)
         hb_bytes = sum(h["bytes_per_step"] for h in hb)
@@ -669,18 +677,20 @@ def main():
             "roofline": dict(family("fwd", IGEMM % (0, 0, 0, 0, 0) + "; the forward launch units of layers 2-30 (the first block's "
                                     "two passes are first_block_kernel<0|1>: kernel_ms_per_step.first_block_fwd)",
                                     ig_ms / max(ig_steps, 1), ig_n / max(ig_steps, 1),
-                                    "HIP events around exactly these launch units INSIDE the timed region (they run alone on "
-                                    "the GPU); achieved / frac = EXECUTED MFMA FLOPs / that time", wino_ms=wino_fwd_ms),
+                                    "HIP events around exactly these launches INSIDE the timed region (they run alone on the "
+                                    "GPU): one pair per launch unit and one per Winograd transform / finishing launch inside it; "
+                                    "achieved / frac = EXECUTED MFMA FLOPs / the GEMM launches' own time",
+                                    ig_wino / max(ig_steps, 1)),
                              traffic=traffic, traffic_source=traffic_src),
             "roofline_dgrad": family("dgrad", IGEMM % (1, 1, 1, 1, 1) + " (+ conv_igemm_kernel<64, 128, 2, 2, 4, 0, 1> for the "
                                      "20-channel head)", ex[1][0], ex[1][2],
                                      "kernel-exclusive: untimed pass with the filter gradients on the same stream "
-                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues", wino_ms=ex[10][0]),
+                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues", ex[10][0]),
             "roofline_wgrad": family("wgrad", "conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs): <256, 128, 3, false, "
                                      "false>, <128, 128, 3, ...>, <128, 64, 4, ...>, <64, 128, 4, ...>, <64, 64, 4, true, false>",
                                      ex[2][0], ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same "
                                      "stream (Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
-                                     "(kernel_ms_per_step.first_block_bwd)", wino_ms=ex[11][0]),
+                                     "(kernel_ms_per_step.first_block_bwd)", ex[11][0]),
             "roofline_bwd": {"bound": "mfma", "kernel": "in the real step: conv dgrad launch units (main stream) overlapped with "
                                                         "conv_wgrad_dma_kernel launch units (second stream)",
                              "achieved": round((exe['dgrad'] + exe['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 if bwd_ms > 0 else 0.0, 2),
@@ -701,8 +711,8 @@ def main():
                 "ms_per_step": round(hb_ms, 3), "bytes_per_step": hb_bytes, "by_family": hb,
                 "traffic": wino_traffic, "traffic_source": wino_traffic_src,
                 "note": "achieved = ALGORITHMIC bytes of these passes (each operand read once, each result written once) / their "
-                        "HIP-event time: forward passes from the untimed all-timers pass (they run alone), backward ones "
-                        "kernel-exclusive (Plan.serial_backward); traffic = fabric bytes per step of the same kernels from the "
+                        "HIP-event time: forward passes inside the timed region (they run alone), backward ones "
+                        "kernel-exclusive in an untimed pass (Plan.serial_backward); traffic = fabric bytes per step of the same kernels from the "
                         "committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), null while the kernels differ from the profiled ones"},
             "kernel_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in prof.items()},
             "final_loss": final_loss,
