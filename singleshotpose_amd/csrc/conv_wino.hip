@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
   constexpr int A = N + 2;
   using M_ = WinoMat<N>;
   typedef float vec __attribute__((ext_vector_type(CV)));
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware order: consecutive workgroups go to the 8 XCDs round robin, each with its own L2 - remapped so that an XCD
+  // walks a contiguous run of tiles and the halo rows / columns neighbouring tiles share (20 of a tile's 36 taps at n = 4)
+  // come out of its L2 instead of being fetched again over the fabric (PMC: 171 MB fetched per launch for 107 MB of input)
+  const int64_t gid = (int64_t)ssp_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x;
   const int cgn = C / CV;
   if (gid >= g.T * cgn) return;
   const unsigned t = ssp_div((unsigned)gid, div_cg);        // T * C / CV < 2^31 is checked by the launcher

@@ -84,7 +84,12 @@ class Darknet(nn.Module):
         # eval forward as one captured hipGraph replay (Plan.forward_graph).  Opt-in: measured no gain on MI355X - the
         # chain is not host-bound (B=1, 672x672: 1.04 ms eager, 36 launches x ~10 us of host time; 1.10 ms replayed)
         self.graph_inference = os.environ.get('SSP_GRAPH_INFERENCE', '0') == '1'
-        self._plan_mem_frac = 0.5
+        # share of the device's HBM the per-shape plan cache may hold (SSP_PLAN_MEM_FRAC).  A rebuilt plan's first step costs
+        # 4-25 ms more than a cached one's (its timed choices are remembered process-wide), i.e. ~3 % of a 10-batch visit of
+        # dataset.py:66-90's schedule, so a miss is cheap and the cache stays small: 0.2 peaks the 16-shape batch-64 soak at
+        # 108 GB reserved (0.5, round 3: 148-157 GB) at the same images/s (profiles/r04_soak_multiscale*.json) - the peak is
+        # one 832 x 832 plan (~70 GB) next to the previous shape's, which lives until the caller drops its last loss tensor
+        self._plan_mem_frac = float(os.environ.get('SSP_PLAN_MEM_FRAC', '0.2'))
 
     # ---- network construction: same module tree as darknet.py:135-249 ----
     def create_network(self, blocks):
@@ -189,6 +194,17 @@ class Darknet(nn.Module):
         if plan is None:
             while len(self._plans) >= self._max_plans:
                 self._plans.popitem(last=False)
+            # make room BEFORE the new plan allocates (its buffers next to an evictee's were the peak of the multi-scale soak):
+            # bytes per input pixel of the plans seen so far (first plan of a process: 1700, batch 64 at 416 x 416 holds 18 GB)
+            budget = self._plan_mem_frac * torch.cuda.get_device_properties(device).total_memory
+            px = float(shape[0] * shape[1] * shape[2])
+            per_px = max([1700.0] + [p.nbytes_now() / float(p.B * p.H * p.W) for p in self._plans.values()])
+            evicted = False
+            while self._plans and per_px * px + sum(max(p.nbytes_est, p.nbytes_now()) for p in self._plans.values()) > budget:
+                self._plans.popitem(last=False)
+                evicted = True
+            if evicted:
+                torch.cuda.empty_cache()
             while True:
                 try:
                     plan = Plan(self, shape[0], shape[1], shape[2], device)

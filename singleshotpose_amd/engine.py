@@ -582,6 +582,9 @@ class Plan(object):
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
+        # the timing / verification scratch (workspaces for the deepest candidate, gradient scratch, twin outputs) goes back
+        # to the driver: left in the caching allocator it sits reserved next to the plan's own buffers (multi-scale soak)
+        torch.cuda.empty_cache()
 
     def _dgrad_key(self, cs):
         return ('dgrad', self.B, cs.H, cs.W, cs.coutp, cs.cin, cs.k, cs.ldraw, cs.inp.ld, _tune_tag())
@@ -850,6 +853,9 @@ class Plan(object):
         torch.cuda.synchronize()
         if len(_TUNE_CACHE) != n_known:
             _tune_cache_save()
+        # the timing / verification scratch (workspaces for the deepest candidate, gradient scratch, twin outputs) goes back
+        # to the driver: left in the caching allocator it sits reserved next to the plan's own buffers (multi-scale soak)
+        torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training, need_grad=False, inline_repack=False):
