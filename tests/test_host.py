@@ -364,3 +364,47 @@ def test_reference_cpu_baseline_harness_runs_from_the_staged_archive():
                          timeout=600, env=dict(os.environ, SSP_REF_FROM_ZIP='1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES=''))
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec['params'] == 50547764 and rec['seconds_per_step']['4'] > 0 and 'modules.zip' in rec['modules']
+
+
+def test_winograd_plan_queries_without_a_gpu():
+    """The host-side sizing queries of the Winograd plans (pure functions of the launch shape: nothing touches the GPU):
+    tile size of a plan code, workspace = (tile+2)^2 * tiles * (Cin + Cout), statistics in the counted format (groups of 16
+    tiles, the groups' pixel counts behind the pairs), and the engine's own view of the codes."""
+    from singleshotpose_amd import _lib
+    from singleshotpose_amd.engine import WINO, WINO4, wino_tile
+    q = _lib.query
+    assert [q('ssp_conv_plan_wino_tile', c) for c in (0, 6413, 312813, 9006413, 9012818, 8006413, 8012814, 10000000)] == \
+        [0, 0, 0, 2, 2, 4, 4, 0]
+    assert [wino_tile(c) for c in (0, 6413, WINO + 6413, WINO4 + 12814)] == [0, 0, 2, 4]
+    B, H, W, Cin, Cout = 64, 13, 13, 1024, 1024
+    for code, tile in ((9006413, 2), (8006413, 4)):
+        T = B * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
+        P = (tile + 2) ** 2
+        assert q('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, code) == P * T * (Cin + Cout)
+        groups = (T + 15) // 16
+        assert q('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, 3, code) == 0
+        assert q('ssp_conv_stats_tiles', B, H, W, Cin, Cout, 3, code) == groups
+        assert q('ssp_conv_stats_floats', B, H, W, Cin, Cout, 3, code) == groups * Cout * 2 + groups
+        assert q('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile) == P * (T * (Cin + Cout) + Cin * Cout)
+    # (tile 2 is what the un-suffixed entry points mean)
+    assert q('ssp_conv_wgrad_wino_workspace_floats', B, H, W, Cin, Cout) == q('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, 2)
+    # a direct plan: rows per statistics tile, pairs only
+    tm = q('ssp_conv_stats_tile_m', B, H, W, Cin, Cout, 3, 0)
+    nt = q('ssp_conv_stats_tiles', B, H, W, Cin, Cout, 3, 0)
+    assert tm in (64, 128) and nt == (B * H * W + tm - 1) // tm
+    assert q('ssp_conv_stats_floats', B, H, W, Cin, Cout, 3, 0) == nt * Cout * 2
+
+
+def test_tune_cache_keys_carry_the_candidate_set(monkeypatch):
+    """A tune-cache entry written with a family of candidates switched off (or before it existed) must not be found by a
+    process that has it on, and the other way round (engine._tune_tag)."""
+    from singleshotpose_amd import engine
+    monkeypatch.delenv('SSP_WINOGRAD', raising=False)
+    monkeypatch.delenv('SSP_WINO_TILES', raising=False)
+    monkeypatch.delenv('SSP_WINO_MIN_CHANNELS', raising=False)
+    both = engine._tune_tag()
+    monkeypatch.setenv('SSP_WINO_TILES', '2')
+    only2 = engine._tune_tag()
+    monkeypatch.setenv('SSP_WINOGRAD', '0')
+    off = engine._tune_tag()
+    assert len({both, only2, off}) == 3
