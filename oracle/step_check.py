@@ -92,6 +92,7 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
     plan = model._plans[(B, H, W, dev.index)]
     # the product's raw conv outputs, NHWC [M][coutp] -> NCHW CPU (backward rewrites them in place: fetch now)
     raws = {}
+    first_raw = None
     for ind, cs in plan.convs.items():
         if getattr(cs, 'first_live', False):
             # first block, fused form: its raw conv output is recomputed by every pass, never stored.  ssp_first_conv_raw
@@ -101,6 +102,7 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             _lib.call('ssp_first_conv_raw', cs.inp.ptr, plan._wbuf(cs).data_ptr(), tmp.data_ptr(), cs.cout, B, cs.H, cs.W,
                       torch.cuda.current_stream().cuda_stream)
             raws[ind] = tmp.view(B, cs.H, cs.W, cs.cout).permute(0, 3, 1, 2).contiguous().cpu()
+            first_raw = (ind, tmp)      # kept on the device: its decisions are frozen below like every other pooled block's
             continue
         r = cs.raw.view(B, cs.H, cs.W, cs.ldraw)[..., :cs.cout].permute(0, 3, 1, 2)
         raws[ind] = r.contiguous().cpu()
@@ -113,7 +115,7 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             acts[ind] = a.t[a.off:].view(-1)[:B * a.H * a.W * a.ld].view(B, a.H, a.W, a.ld)[..., :cs.cout] \
                 .permute(0, 3, 1, 2).contiguous().cpu() if a.off == 0 else None
     acts = {k: v for k, v in acts.items() if v is not None}
-    # pooled blocks (but the fused first one, whose raw output is never stored): the product's own BN + leaky kernel once
+    # pooled blocks (the fused first one, whose raw output is never stored, follows below): the product's own BN + leaky kernel once
     # more WITHOUT the pooling, into a scratch buffer - its signs freeze the leaky branches, its first-maximum positions the
     # pool winners (forward_ref(pool_override=...)).  Same kernel, same scale / shift vectors, same expression as the
     # pooled launch of the forward pass and the recomputation in backward.
@@ -130,6 +132,30 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             acts[ind] = a
             pools[ind + 1] = F.max_pool2d(a, 2, 2, return_indices=True)[1]
             del scratch
+    if first_raw is not None:
+        # ... and the fused first block: the same BN + leaky expression (scale * raw + shift, leaky) over the raw values its
+        # four passes recompute (ssp_first_conv_raw: bit-identical), un-pooled, in 16-image slices (the map is 1.4 GB at batch
+        # 64): leaky signs and first-maximum pool winners of the product.  Without this the oracle took its OWN decisions on
+        # the first block, and a handful of flipped elements among its tens of millions moved the first block's
+        # BatchNorm-bias gradient by 1e-4 ... 1e-2 at some shapes (tools/multiscale_check.py, 288 and 544 at batch 8).
+        ind, tmp = first_raw
+        cs = plan.convs[ind]
+        if cs.pool and cs.needs_act and cs.slope == 0.1:
+            v = cs.vec
+            parts = []
+            step_b = 16
+            for b0 in range(0, B, step_b):
+                nb = min(step_b, B - b0)
+                scratch = torch.empty(nb * cs.H * cs.W * cs.cout, dtype=torch.float32, device=dev)
+                _lib.call('ssp_bn_act_fwd', tmp.data_ptr() + 4 * b0 * cs.H * cs.W * cs.cout, cs.cout, scratch.data_ptr(), cs.cout,
+                          v[2].data_ptr(), v[3].data_ptr(), cs.cout, nb, cs.H, cs.W, 0, cs.slope,
+                          torch.cuda.current_stream().cuda_stream)
+                parts.append(scratch.view(nb, cs.H, cs.W, cs.cout).permute(0, 3, 1, 2).contiguous().cpu())
+                del scratch
+            a = torch.cat(parts, 0)
+            acts[ind] = a
+            pools[ind + 1] = F.max_pool2d(a, 2, 2, return_indices=True)[1]
+        del tmp
     loss = crit(out, tgt, epoch)
     loss.backward()
     torch.cuda.synchronize()
