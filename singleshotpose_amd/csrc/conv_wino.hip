@@ -213,27 +213,46 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
 // kernel replaces read 9 of 16 planes per output pixel: 2.25 x the bytes, all of them fabric traffic on the deep layers).
 // BatchNorm statistics: per tile GROUP and channel (mean, M2) of the valid pixels, plus the group's pixel count (the maps'
 // odd edges make it vary) behind the pairs: stats [groups][Cout][2] | counts [groups] - bn_fwd_finalize's counted format.
-template <int N>
+// CS = channel quads per workgroup (16: a 64-channel slab, 16 tiles side by side; 64: a 256-channel slab, 4 tiles side by
+// side, the group's 16 tiles in 4 passes): a tile row of the slab is one contiguous piece of a plane - 256 bytes or 1 KiB.
+template <int N, int CS>
 __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeom g) {
   constexpr int A = N + 2;
+  constexpr int TP = 256 / CS;                 // tiles per pass
+  constexpr int NP = SSP_WINO_TG / TP;         // passes over the group
   using M_ = WinoMat<N>;
-  const int tid = threadIdx.x, gl = tid & 15, tl = tid >> 4;
-  const int c = blockIdx.y * 64 + gl * 4;
-  const int64_t t64 = (int64_t)blockIdx.x * SSP_WINO_TG + tl;
-  const bool live = (c < p.Cout) && (t64 < g.T);        // Cout % 4 == 0 on this path (checked by the launcher)
+  const int tid = threadIdx.x, gl = tid % CS, tl = tid / CS;
+  const int c = blockIdx.y * (CS * 4) + gl * 4;
+  const bool cok = c < p.Cout;                 // Cout % 4 == 0 on this path (checked by the launcher)
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Y[N][N];
+  f32x4 b4 = z4, e4 = {1.f, 1.f, 1.f, 1.f};
+  if (cok && p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
+  if (cok && p.escale != nullptr) e4 = *reinterpret_cast<const f32x4*>(p.escale + c);
+  const bool bnb = p.bn_partial != nullptr;
+  const bool want_stats = p.stats != nullptr;
+  f32x4 bsc = z4, bsh = z4, bmu = z4, bis = z4, s1 = z4, s2 = z4;
+  if (bnb && cok) {
+    bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + c); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + c);
+    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + c); bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + c);
+  }
+  // running (count, mean, M2) of this thread's tiles, Chan-combined tile by tile
+  float rn = 0.f;
+  f32x4 rmean = z4, rm2 = z4;
+#pragma unroll 1
+  for (int pass = 0; pass < NP; ++pass) {
+    const int64_t t64 = (int64_t)blockIdx.x * SSP_WINO_TG + pass * TP + tl;
+    const bool live = cok && (t64 < g.T);
+    if (!live) continue;
+    f32x4 Y[N][N];
 #pragma unroll
-  for (int i = 0; i < N; ++i)
+    for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int j = 0; j < N; ++j) Y[i][j] = z4;
-  int b = 0, ty = 0, tx = 0;
-  if (live) {
+      for (int j = 0; j < N; ++j) Y[i][j] = z4;
     const unsigned t = (unsigned)t64;
     const unsigned q = ssp_div(t, g.div_tw);
-    tx = (int)(t - q * (unsigned)g.tw);
-    b = (int)ssp_div(q, g.div_th);
-    ty = (int)(q - (unsigned)b * (unsigned)g.th);
+    const int tx = (int)(t - q * (unsigned)g.tw);
+    const int b = (int)ssp_div(q, g.div_th);
+    const int ty = (int)(q - (unsigned)b * (unsigned)g.th);
     const float* src = p.Mw + t64 * p.Cout + c;
     const int64_t plane = g.T * p.Cout;
     // row i of the transform domain at a time: rr = M[i][:] A (n values), then Y[:][q] += A^T[:][i] rr[q]
@@ -255,61 +274,69 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
         });
       });
     });
-  }
-  f32x4 b4 = z4, e4 = {1.f, 1.f, 1.f, 1.f};
-  if (live && p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
-  if (live && p.escale != nullptr) e4 = *reinterpret_cast<const f32x4*>(p.escale + c);
-  const bool bnb = p.bn_partial != nullptr;
-  f32x4 bsc = z4, bsh = z4, bmu = z4, bis = z4, s1 = z4, s2 = z4;
-  if (bnb && live) {
-    bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + c); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + c);
-    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + c); bis = *reinterpret_cast<const f32x4*>(p.bn_invstd + c);
-  }
-  // statistics of the raw (bias-free) values: two passes over the registers (count and mean, then M2)
-  float cnt = 0.f;
-  f32x4 sum = z4;
-  const bool want_stats = p.stats != nullptr;
+    // the tile's valid pixels: epilogue + statistics of the raw (bias-free) values (count and mean, then M2)
+    float cnt = 0.f;
+    f32x4 sum = z4;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int y = N * ty + i;
+    for (int i = 0; i < N; ++i) {
+      const int y = N * ty + i;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int x = N * tx + j;
-      if (live && y < g.H && x < g.W) {
-        const f32x4 v = Y[i][j];
-        cnt += 1.f;
-        sum += v;
-        const int64_t m = ((int64_t)b * g.H + y) * g.W + x;
-        float* dst = p.out + m * p.ldout + c;
-        f32x4 o = v * e4 + b4;
+      for (int j = 0; j < N; ++j) {
+        const int x = N * tx + j;
+        if (y < g.H && x < g.W) {
+          const f32x4 v = Y[i][j];
+          cnt += 1.f;
+          sum += v;
+          const int64_t m = ((int64_t)b * g.H + y) * g.W + x;
+          float* dst = p.out + m * p.ldout + c;
+          f32x4 o = v * e4 + b4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : o[k] * p.act_slope;
-        if (p.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = o;
-        if (bnb) {
-          const f32x4 xr = *reinterpret_cast<const f32x4*>(p.bn_raw + m * p.bn_ld + c);
+          for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : o[k] * p.act_slope;
+          if (p.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = o;
+          if (bnb) {
+            const f32x4 xr = *reinterpret_cast<const f32x4*>(p.bn_raw + m * p.bn_ld + c);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float yy = xr[k] * bsc[k] + bsh[k];
-            const float dyv = yy > 0.f ? o[k] : o[k] * p.bn_slope;
-            s1[k] += dyv;
-            s2[k] += dyv * ((xr[k] - bmu[k]) * bis[k]);
+            for (int k = 0; k < 4; ++k) {
+              const float yy = xr[k] * bsc[k] + bsh[k];
+              const float dyv = yy > 0.f ? o[k] : o[k] * p.bn_slope;
+              s1[k] += dyv;
+              s2[k] += dyv * ((xr[k] - bmu[k]) * bis[k]);
+            }
           }
         }
       }
     }
+    if (want_stats && cnt > 0.f) {
+      const f32x4 mean = sum * (1.f / cnt);
+      f32x4 m2 = z4;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          if (N * ty + i < g.H && N * tx + j < g.W) {
+            const f32x4 dd = Y[i][j] - mean;
+            m2 += dd * dd;
+          }
+      const float nt = rn + cnt, f = cnt / nt;
+      const f32x4 dd = mean - rmean;
+      rmean += dd * f;
+      rm2 += m2 + dd * dd * (rn * f);
+      rn = nt;
+    }
   }
-  __shared__ float red[16][16][9];   // [tile lane][channel quad][cnt, mean x4, m2 x4]  (or [-, s1 x4, s2 x4])
+  __shared__ float red[TP][CS][9];   // [tile lane][channel quad][cnt, mean x4, m2 x4]  (or [-, s1 x4, s2 x4])
   if (bnb) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { red[tl][gl][1 + k] = s1[k]; red[tl][gl][5 + k] = s2[k]; }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < CS * 4) {
       const int q = tid >> 2, k = tid & 3;
-      const int ch = blockIdx.y * 64 + tid;
+      const int ch = blockIdx.y * (CS * 4) + tid;
       if (ch < p.Cout) {
         float a = 0.f, bb = 0.f;
-        for (int w = 0; w < 16; ++w) { a += red[w][q][1 + k]; bb += red[w][q][5 + k]; }
+#pragma unroll
+        for (int w = 0; w < TP; ++w) { a += red[w][q][1 + k]; bb += red[w][q][5 + k]; }
         if ((int)gridDim.x > p.bn_nslot) {
           float* dst = p.bn_partial + ((int64_t)(blockIdx.x % p.bn_nslot) * p.Cout + ch) * 2;
           atomicAdd(dst, a);
@@ -324,28 +351,17 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
     return;
   }
   if (!want_stats) return;
-  f32x4 mean = z4, m2 = z4;
-  if (cnt > 0.f) {
-    mean = sum * (1.f / cnt);
+  red[tl][gl][0] = rn;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        if (N * ty + i < g.H && N * tx + j < g.W) {
-          const f32x4 dd = Y[i][j] - mean;
-          m2 += dd * dd;
-        }
-  }
-  red[tl][gl][0] = cnt;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { red[tl][gl][1 + k] = mean[k]; red[tl][gl][5 + k] = m2[k]; }
+  for (int k = 0; k < 4; ++k) { red[tl][gl][1 + k] = rmean[k]; red[tl][gl][5 + k] = rm2[k]; }
   __syncthreads();
-  if (tid < 64) {                     // one thread per channel of the slab
+  if (tid < CS * 4) {                     // one thread per channel of the slab
     const int q = tid >> 2, k = tid & 3;
-    const int ch = blockIdx.y * 64 + tid;
+    const int ch = blockIdx.y * (CS * 4) + tid;
     if (ch < p.Cout) {
       float n_ = red[0][q][0], mu = red[0][q][1 + k], ss = red[0][q][5 + k];
-      for (int w = 1; w < 16; ++w) {
+#pragma unroll
+      for (int w = 1; w < TP; ++w) {
         const float nb = red[w][q][0], mb = red[w][q][1 + k], m2b = red[w][q][5 + k];
         const float nt = n_ + nb;
         if (nt > 0.f) {
@@ -558,9 +574,14 @@ int ssp_wino_output_launch(const WinoOutArgs& a, int B, int H, int W, int tile, 
   const WinoGeom g = wino_geom(B, H, W, tile);
   const int P = ssp_wino_planes(tile);
   SspProfScope prof(prof_kind, stream, 4.0 * a.Cout * ((double)B * H * W * (a.accumulate ? 2.0 : 1.0) * (a.bn_partial ? 2.0 : 1.0) + (double)P * g.T));
-  const dim3 grid((unsigned)((g.T + SSP_WINO_TG - 1) / SSP_WINO_TG), (unsigned)ssp_cdiv(a.Cout, 64));
-  if (tile == 2) hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, stream, a, g);
-  else hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, stream, a, g);
+  // 64-channel slabs.  256-channel slabs (1 KiB pieces of a plane per tile row; wino_variant bit 2) measured no better on
+  // any layer and 5-10 % worse on the 52 x 52 / 26 x 26 ones (profiles/r04_wino_xform_variants.txt): experiment switch only
+  const bool wide = a.Cout >= 256 && (ssp_option(SSP_OPT_WINO_VARIANT) & 4);
+  const dim3 grid((unsigned)((g.T + SSP_WINO_TG - 1) / SSP_WINO_TG), (unsigned)ssp_cdiv(a.Cout, wide ? 256 : 64));
+  if (tile == 2 && wide) hipLaunchKernelGGL((wino_output_kernel<2, 64>), grid, dim3(256), 0, stream, a, g);
+  else if (tile == 2) hipLaunchKernelGGL((wino_output_kernel<2, 16>), grid, dim3(256), 0, stream, a, g);
+  else if (wide) hipLaunchKernelGGL((wino_output_kernel<4, 64>), grid, dim3(256), 0, stream, a, g);
+  else hipLaunchKernelGGL((wino_output_kernel<4, 16>), grid, dim3(256), 0, stream, a, g);
   SSP_CHECK_LAUNCH("wino_output");
   return SSP_OK;
 }
