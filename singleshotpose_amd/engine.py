@@ -1004,24 +1004,31 @@ class Plan(object):
                     ev = side.record_event()
                     for cs, _ in group:
                         wait_for[cs.ind] = ev
-        # Host issue order: the forward filter transforms are queued layer by layer, a few layers ahead of the conv that needs
-        # them, and the data-gradient operands after the last forward launch (they only have to be ready when backward
-        # starts) - so that the main stream's first launches are not queued behind ~70 side-stream launches.  In a traced
-        # batch-8 step that queueing delayed the first forward kernel by 0.65 ms (profiles/r04_timeline_b8.txt); in steady
-        # state the host queues a step in 3.6 ms (tools/host_issue_time.py) against 6.0 ms of GPU time at batch 8 and 28 ms
-        # at batch 64, runs ahead of the GPU either way, and the step time did not move (6.03 / 28.03 ms) - kept because it
-        # is the order the dependencies suggest, not because it pays.
-        wino_pending = list(wino) if (stale or need_grad or wino) else []
-
-        def issue_side(upto_ind):
-            while wino_pending and wino_pending[0][0].ind <= upto_ind:
-                cs, wkey = wino_pending.pop(0)
-                src = cs.conv.weight if cs.packed else self._wbuf(cs)
-                tile = wino_tile(cs.plan_fwd)
-                call('ssp_wino_filter_transform_t', src.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp,
-                     tile, side.cuda_stream)
-                self.wino_version[cs.ind] = wkey
-                wait_for[cs.ind] = side.record_event()
+        if stale or need_grad or wino:
+            # the forward filter transforms of every Winograd layer, queued up front: they depend on the weights only and
+            # run under the first block and layer 2.  (Queueing them layer by layer just ahead of their convs, and the
+            # data-gradient operands after the last forward launch, was tried for the host-bound look of a traced batch-8
+            # step - profiles/r04_timeline_b8.txt: first kernel 0.65 ms late - and bought nothing: the host queues a step in
+            # 3.6 ms, tools/host_issue_time.py, against 6 ms of GPU time at batch 8 and 28 ms at batch 64 - it runs ahead of the
+            # GPU either way and the step time did not move.)
+            if wino:
+                for cs, wkey in wino:
+                    src = cs.conv.weight if cs.packed else self._wbuf(cs)
+                    tile = wino_tile(cs.plan_fwd)
+                    call('ssp_wino_filter_transform_t', src.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp,
+                         tile, side.cuda_stream)
+                    self.wino_version[cs.ind] = wkey
+                ev = side.record_event()
+                for cs, _ in wino:
+                    wait_for[cs.ind] = ev
+        if need_grad:
+            for ind in sorted(self.convs.keys(), reverse=True):
+                cs = self.convs[ind]
+                if not cs.first:
+                    self._repack_dgrad(cs, side)
+            self.dgrad_ready = side.record_event()
+        else:
+            self.dgrad_ready = None
         waited = set()
         if training:
             self.net._bn_epoch += 1       # running statistics change below: every plan's inference constants are stale
@@ -1029,7 +1036,6 @@ class Plan(object):
             kind = op[0]
             if kind == 'conv':
                 cs = op[1]
-                issue_side(cs.ind + 5)          # this conv's transformed filters and those of the next two or three convs
                 ev = wait_for.get(cs.ind)
                 if ev is not None and id(ev) not in waited:
                     torch.cuda.current_stream().wait_event(ev)      # this layer's packed filters are ready
@@ -1107,14 +1113,6 @@ class Plan(object):
                 for s in srcs:
                     call('ssp_copy_channels', s.ptr, s.ld, _ptr(out.t, off), out.ld, s.C, B * s.H * s.W, 0, st)
                     off += s.C
-        if need_grad:
-            for ind in sorted(self.convs.keys(), reverse=True):
-                cs = self.convs[ind]
-                if not cs.first:
-                    self._repack_dgrad(cs, side)
-            self.dgrad_ready = side.record_event()
-        else:
-            self.dgrad_ready = None
         if join_side and self.side_stream is not None:
             # captured chain: every forked stream rejoins (the data-gradient operand repacks included)
             if not self._sg_serial:
