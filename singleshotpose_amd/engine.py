@@ -1018,6 +1018,9 @@ class Plan(object):
                     call('ssp_wino_filter_transform_t', src.data_ptr(), self._wino_u(cs, tile).data_ptr(), cs.cout, cs.cinp,
                          tile, side.cuda_stream)
                     self.wino_version[cs.ind] = wkey
+                # ONE event behind all of them: the side stream is through by ~1.4 ms, the main stream reaches layer 4 at
+                # ~1.6 ms, and every cross-stream wait costs ~17 us of GPU idle even when its event has long fired (one
+                # event per layer: 13 such gaps, forward idle 0.68 ms instead of 0.3-0.6, profiles/r04_timeline.txt)
                 ev = side.record_event()
                 for cs, _ in wino:
                     wait_for[cs.ind] = ev
