@@ -611,7 +611,7 @@ def main():
                            ('wgrad', int(getattr(cs, 'wgrad_wino', 0) or 0))):
                 alg[fam] += direct
                 if n:
-                    tiles = B * ((cs.H + n - 1) // n) * ((cs.W + n - 1) // n)
+                    tiles = _lib.query('ssp_conv_wino_tiles', B, cs.H, cs.W, n)      # (the 2 x 2 image mosaic included)
                     exe[fam] += 2.0 * (n + 2) ** 2 * tiles * cs.cin * cs.cout
                     wino_layers[fam][n].append(ind)
                 else:

@@ -48,7 +48,7 @@ int ssp_set_option(const char* name, int value);
  *   8000000 + the same = Winograd F(4x4, 3x3) (points 0, 1, -1, 1/2, -2): 36/144 of the multiplies, result within ~5e-6 of its
  *   range (about twice the direct fp32 kernel's own rounding error).  `wt` must then be the TRANSFORMED filter from
  *   ssp_wino_filter_transform_t with the plan's tile size (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the
- *   workspace (ssp_conv_workspace_floats: (tile+2)^2 * tiles * (Cin + Cout) floats, tiles = B * ceil(H/tile) * ceil(W/tile))
+ *   workspace (ssp_conv_workspace_floats: (tile+2)^2 * tiles * (Cin + Cout) floats, tiles = ssp_conv_wino_tiles(B, H, W, tile))
  *   is mandatory; a Winograd code on a shape it does not fit is an error, not a fallback (the filter operand differs).
  *   Valid for ssp_conv_fwd, ssp_conv_fwd_affine, ssp_conv_dgrad and ssp_conv_dgrad_bnbwd.
  * stats of a Winograd plan are in the COUNTED format: ssp_conv_stats_tile_m returns 0, the buffer holds
@@ -70,6 +70,11 @@ int ssp_conv_stats_tiles(int B, int H, int W, int Cin, int Cout, int R, int plan
 int64_t ssp_conv_stats_floats(int B, int H, int W, int Cin, int Cout, int R, int plan);
 /* tile size of a plan code: 2 or 4 for a Winograd plan, 0 otherwise */
 int ssp_conv_plan_wino_tile(int plan);
+/* tiles (rows of each of the (tile+2)^2 batched GEMMs) a Winograd launch of that tile size cuts B maps of H x W into:
+ * B * ceil(H/tile) * ceil(W/tile), or - when that needs fewer - ceil(B/4) * ceil((2H+1)/tile) * ceil((2W+1)/tile): four
+ * images tiled as one 2 x 2 mosaic with a zero row / column between them (13 x 13 at tile 4: 49 tiles per four images
+ * instead of 64).  What the workspace and statistics queries are built on. */
+int64_t ssp_conv_wino_tiles(int B, int H, int W, int tile);
 /* U[xi][row][k] = (G g G^T)[xi], xi = 0..(tile+2)^2-1, of the 3x3 filters g[tap] = w9[row][tap][k] (rows x 9 x K floats,
  * K % 4 == 0): the filter operand of a Winograd plan of that tile size (2 or 4).  rows = Cout, K = Cin for the forward
  * layout; rows = Cin_dx, K = Cout_dy for the data-gradient layout.  U: (tile+2)^2 * rows * K floats.

@@ -33,6 +33,7 @@ _SIGS = {
     "ssp_conv_stats_tiles": [I, I, I, I, I, I, I],
     "ssp_conv_stats_floats": [I, I, I, I, I, I, I],
     "ssp_conv_plan_wino_tile": [I],
+    "ssp_conv_wino_tiles": [I, I, I, I],
     "ssp_wino_filter_transform": [P, P, I, I, P],
     "ssp_wino_filter_transform_t": [P, P, I, I, I, P],
     "ssp_conv_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
@@ -83,7 +84,7 @@ _SIGS = {
 }
 
 _RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats_t',
-          'ssp_conv_stats_floats')
+          'ssp_conv_stats_floats', 'ssp_conv_wino_tiles')
 
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
               "first_block_bwd", "wino_fwd", "wino_dgrad", "wino_wgrad")

@@ -76,19 +76,45 @@ template <> struct WinoMat<4> {
                                      {0.f, 1.f, -1.f, 0.125f, -8.f, 1.f}};
 };
 
-// tile t = (b * th + ty) * tw + tx covers output pixels (n ty .. n ty + n - 1, n tx .. n tx + n - 1) of image b
+// Tiling of the maps.  Plain (G = 1): tile t = (b * th + ty) * tw + tx covers output pixels (n ty .. n ty + n - 1,
+// n tx .. n tx + n - 1) of image b, th = ceil(H / n).  A map whose edge is one pixel more than a multiple of n wastes most of
+// its last tile row and column: 13 x 13 at n = 4 takes 4 x 4 tiles = 256 computed pixels for 169 (1.51 x), and the six
+// 13 x 13 layers are half of the network's FLOPs.  MOSAIC (G = 2): four consecutive images are laid out 2 x 2 with ONE zero
+// row / column between them - exactly the zero padding a 3 x 3 filter sees at an image border - and the (2H + 1) x (2W + 1)
+// mosaic is tiled as one map: 27 x 27 -> 7 x 7 tiles for FOUR images, 49 instead of 64 (12.25 per image: 1.16 x).  Only the
+// gather of the input / output-gradient transforms and the scatter of the finishing pass know about it (a window or tile that
+// straddles two images reads each pixel from its own image, the gap row reads as zero and its outputs are dropped); the
+// GEMMs just see fewer tile rows.  Chosen whenever it needs fewer tiles (a pure function of the launch shape: every query
+// and launcher agrees): H = W = 13 (416 x 416 input) and 21 (valid.py's 672 x 672) at n = 4, 9 / 17 / 25 of the multi-scale
+// schedule; never for maps that tile exactly or batches where the phantom images of the last mosaic outweigh the gain.
 struct WinoGeom {
   int H, W, th, tw;
   int64_t T;
   SspFastDiv div_tw, div_th;
+  int G, B;      // G = 1: plain, 2: 2 x 2 mosaic of images; B = images (the last mosaic may hold phantom ones)
 };
 static WinoGeom wino_geom(int B, int H, int W, int tile) {
   WinoGeom g;
-  g.H = H; g.W = W;
+  g.H = H; g.W = W; g.B = B; g.G = 1;
   g.th = (H + tile - 1) / tile; g.tw = (W + tile - 1) / tile;
   g.T = (int64_t)B * g.th * g.tw;
+  const int mth = (2 * H + 1 + tile - 1) / tile, mtw = (2 * W + 1 + tile - 1) / tile;
+  const int64_t mT = (int64_t)((B + 3) / 4) * mth * mtw;
+  if (mT < g.T) { g.G = 2; g.th = mth; g.tw = mtw; g.T = mT; }
   g.div_tw = ssp_fastdiv((unsigned)g.tw); g.div_th = ssp_fastdiv((unsigned)g.th);
   return g;
+}
+// mosaic position (Y, X) of mosaic (or image, G = 1) mb -> image b and pixel (y, x); false: padding, gap or phantom image
+__device__ __forceinline__ bool wino_map(const WinoGeom& g, int mb, int Y, int X, int& b, int& y, int& x) {
+  if (g.G == 1) {
+    b = mb; y = Y; x = X;
+    return ((unsigned)Y < (unsigned)g.H) && ((unsigned)X < (unsigned)g.W);
+  }
+  const int iy = Y > g.H ? 1 : 0, ix = X > g.W ? 1 : 0;
+  y = Y - iy * (g.H + 1);
+  x = X - ix * (g.W + 1);
+  b = mb * 4 + iy * 2 + ix;
+  return (Y >= 0) && (X >= 0) && (y < g.H) && (x < g.W) && (b < g.B);
 }
 
 // ---- V = B^T d B: thread = (tile, CV channels) -------------------------------------------------------------------------
@@ -107,24 +133,23 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
   if (gid >= g.T * cgn) return;
   const unsigned t = ssp_div((unsigned)gid, div_cg);        // T * C / CV < 2^31 is checked by the launcher
   const int c = (int)((unsigned)gid - t * (unsigned)cgn) * CV;
-  const unsigned q = ssp_div(t, g.div_tw);                  // b * th + ty
+  const unsigned q = ssp_div(t, g.div_tw);                  // mb * th + ty
   const int tx = (int)(t - q * (unsigned)g.tw);
-  const unsigned b = ssp_div(q, g.div_th);
-  const int ty = (int)(q - b * (unsigned)g.th);
+  const unsigned mb = ssp_div(q, g.div_th);                 // image (plain) or mosaic of four
+  const int ty = (int)(q - mb * (unsigned)g.th);
   const int y0 = N * ty - 1, x0 = N * tx - 1;
-  const float* base = in + ((int64_t)b * g.H * g.W) * ldin + c;
+  const float* base = in + c;
   vec d[A][A];
 #pragma unroll
   for (int i = 0; i < A; ++i) {
-    const int y = y0 + i;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      const int x = x0 + j;
-      const bool ok = ((unsigned)y < (unsigned)g.H) && ((unsigned)x < (unsigned)g.W);
+      int b, y, x;
+      const bool ok = wino_map(g, (int)mb, y0 + i, x0 + j, b, y, x);
       vec z;
 #pragma unroll
       for (int k = 0; k < CV; ++k) z[k] = 0.f;
-      d[i][j] = ok ? *reinterpret_cast<const vec*>(base + ((int64_t)y * g.W + x) * ldin) : z;
+      d[i][j] = ok ? *reinterpret_cast<const vec*>(base + (((int64_t)b * g.H + y) * g.W + x) * ldin) : z;
     }
   }
   // r = B^T d (over the rows), then V = r B (the same combination over the columns)
@@ -251,8 +276,8 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
     const unsigned t = (unsigned)t64;
     const unsigned q = ssp_div(t, g.div_tw);
     const int tx = (int)(t - q * (unsigned)g.tw);
-    const int b = (int)ssp_div(q, g.div_th);
-    const int ty = (int)(q - (unsigned)b * (unsigned)g.th);
+    const int mb = (int)ssp_div(q, g.div_th);
+    const int ty = (int)(q - (unsigned)mb * (unsigned)g.th);
     const float* src = p.Mw + t64 * p.Cout + c;
     const int64_t plane = g.T * p.Cout;
     // row i of the transform domain at a time: rr = M[i][:] A (n values), then Y[:][q] += A^T[:][i] rr[q]
@@ -277,13 +302,14 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
     // the tile's valid pixels: epilogue + statistics of the raw (bias-free) values (count and mean, then M2)
     float cnt = 0.f;
     f32x4 sum = z4;
+    unsigned valid = 0u;      // bit i * N + j: output (i, j) of the tile is a pixel of a real image
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int y = N * ty + i;
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        const int x = N * tx + j;
-        if (y < g.H && x < g.W) {
+        int b, y, x;
+        if (wino_map(g, mb, N * ty + i, N * tx + j, b, y, x)) {
+          valid |= 1u << (i * N + j);
           const f32x4 v = Y[i][j];
           cnt += 1.f;
           sum += v;
@@ -314,7 +340,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(WinoOutArgs p, WinoGeo
       for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j)
-          if (N * ty + i < g.H && N * tx + j < g.W) {
+          if ((valid >> (i * N + j)) & 1u) {
             const f32x4 dd = Y[i][j] - mean;
             m2 += dd * dd;
           }
@@ -397,19 +423,20 @@ __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restri
   const int c = (int)((unsigned)gid - t * (unsigned)cgn) * CV;
   const unsigned q = ssp_div(t, g.div_tw);
   const int tx = (int)(t - q * (unsigned)g.tw);
-  const unsigned b = ssp_div(q, g.div_th);
-  const int ty = (int)(q - b * (unsigned)g.th);
-  const float* base = dy + ((int64_t)b * g.H * g.W) * lddy + c;
+  const unsigned mb = ssp_div(q, g.div_th);
+  const int ty = (int)(q - mb * (unsigned)g.th);
+  const float* base = dy + c;
   vec d[N][N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const int y = N * ty + i, x = N * tx + j;
+      int b, y, x;
+      const bool ok = wino_map(g, (int)mb, N * ty + i, N * tx + j, b, y, x);
       vec z;
 #pragma unroll
       for (int k = 0; k < CV; ++k) z[k] = 0.f;
-      d[i][j] = (y < g.H && x < g.W) ? *reinterpret_cast<const vec*>(base + ((int64_t)y * g.W + x) * lddy) : z;
+      d[i][j] = ok ? *reinterpret_cast<const vec*>(base + (((int64_t)b * g.H + y) * g.W + x) * lddy) : z;
     }
   // r = A d (A = (A^T)^T: r[i][q] = sum_p AT[p][i] d[p][q]), then dM = r A^T
   vec r[A][N];
@@ -495,7 +522,7 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline bool wino_tile_ok(int tile) { return tile == 2 || tile == 4; }
-int64_t ssp_wino_tiles(int B, int H, int W, int tile) { return (int64_t)B * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
+int64_t ssp_wino_tiles(int B, int H, int W, int tile) { return wino_geom(B, H, W, tile).T; }
 int ssp_wino_planes(int tile) { return (tile + 2) * (tile + 2); }
 int64_t ssp_wino_stat_groups(int B, int H, int W, int tile) { return (ssp_wino_tiles(B, H, W, tile) + SSP_WINO_TG - 1) / SSP_WINO_TG; }
 

@@ -191,6 +191,10 @@ int ssp_conv_stats_tile_m(int B, int H, int W, int Cin, int Cout, int R, int pla
   return ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan);
 }
 int ssp_conv_plan_wino_tile(int plan) { return ssp_wino_plan_tile(plan); }
+int64_t ssp_conv_wino_tiles(int B, int H, int W, int tile) {
+  if (tile != 2 && tile != 4) return 0;
+  return ssp_wino_tiles(B, H, W, tile);
+}
 int ssp_conv_stats_tiles(int B, int H, int W, int Cin, int Cout, int R, int plan) {
   if (const int tile = ssp_wino_plan_tile(plan)) return (int)ssp_wino_stat_groups(B, H, W, tile);
   return ssp_cdiv((int64_t)B * H * W, ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan));

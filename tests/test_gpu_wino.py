@@ -47,6 +47,11 @@ CASES = [
     (64, 13, 13, 256, 512, 0, False, WINO4),       # benchmark grid: 1024 tiles per transform position
     (2, 1, 5, 64, 128, 0, False, WINO4),
     (4, 52, 52, 128, 256, 0, False, WINO4),        # 13 x 13 exact tiles, the K = 128 GEMMs of layers 8 / 10
+    # 2 x 2 image mosaics (four images tiled as one map with a zero row / column between them: fewer tiles)
+    (7, 13, 13, 64, 128, 0, False, WINO4),         # two mosaics, the second with one phantom image
+    (4, 21, 21, 128, 128, 16, True, WINO4),        # valid.py's grid: 121 tiles instead of 144; bias, sliced output
+    (3, 9, 9, 32, 128, 0, False, WINO4),           # one mosaic, one phantom image
+    (4, 13, 9, 64, 192, 0, False, WINO4),          # non-square
 ]
 
 
@@ -129,7 +134,7 @@ def test_wino_conv_fwd_affine_eval_block(WINO):
 
 
 @pytest.mark.parametrize("WINO", [WINO, WINO4])
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 128, 256), (3, 10, 14, 256, 128), (64, 13, 13, 128, 512)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 128, 256), (3, 10, 14, 256, 128), (64, 13, 13, 128, 512), (7, 13, 9, 128, 128)])
 def test_wino_conv_dgrad(B, H, W, Cin, Cout, WINO):
     """Data gradient with a Winograd plan: filters from the ssp_repack_dgrad layout; plain, accumulating, and with the
     BatchNorm-backward reductions of the producing block folded into the finishing pass (ssp_conv_dgrad_bnbwd)."""
@@ -183,7 +188,7 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout, WINO):
 
 @pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 13, 13, 128, 256), (3, 10, 14, 256, 64), (64, 13, 13, 256, 512), (16, 7, 9, 64, 192),
-                                            (64, 13, 13, 512, 1024)])
+                                            (64, 13, 13, 512, 1024), (7, 21, 13, 64, 128)])
 def test_wino_conv_wgrad(B, H, W, Cin, Cout, tile):
     """Filter gradient in the Winograd domain (ssp_conv_wgrad_wino) against autograd of F.conv2d and against the direct
     kernel; accumulates into dw (a second call doubles it)."""

@@ -377,8 +377,14 @@ def test_winograd_plan_queries_without_a_gpu():
         [0, 0, 0, 2, 2, 4, 4, 0]
     assert [wino_tile(c) for c in (0, 6413, WINO + 6413, WINO4 + 12814)] == [0, 0, 2, 4]
     B, H, W, Cin, Cout = 64, 13, 13, 1024, 1024
+    # tiles: plain B * ceil(H/n) * ceil(W/n), or the 2 x 2 image mosaic when it needs fewer (13 x 13 at n = 4: 49 per 4 images)
+    assert q('ssp_conv_wino_tiles', 64, 13, 13, 4) == 16 * 49 and q('ssp_conv_wino_tiles', 64, 13, 13, 2) == 64 * 49
+    assert q('ssp_conv_wino_tiles', 64, 26, 26, 4) == 64 * 49 and q('ssp_conv_wino_tiles', 64, 52, 52, 4) == 64 * 169
+    assert q('ssp_conv_wino_tiles', 1, 21, 21, 4) == 36 and q('ssp_conv_wino_tiles', 4, 21, 21, 4) == 121
+    assert q('ssp_conv_wino_tiles', 7, 13, 13, 4) == 2 * 49 and q('ssp_conv_wino_tiles', 5, 13, 13, 4) == 5 * 16
+    assert q('ssp_conv_wino_tiles', 4, 13, 9, 4) == 7 * 5 and q('ssp_conv_wino_tiles', 8, 13, 13, 3) == 0
     for code, tile in ((9006413, 2), (8006413, 4)):
-        T = B * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
+        T = q('ssp_conv_wino_tiles', B, H, W, tile)
         P = (tile + 2) ** 2
         assert q('ssp_conv_workspace_floats', B, H, W, Cin, Cout, 3, code) == P * T * (Cin + Cout)
         groups = (T + 15) // 16
