@@ -10,6 +10,7 @@ forward never calls them.  All device work goes through libssp_hip.so (engine.Pl
 fallback: a CPU tensor or a missing library raises.
 """
 import collections
+import gc
 import os
 
 import numpy as np
@@ -204,6 +205,7 @@ class Darknet(nn.Module):
                 self._plans.popitem(last=False)
                 evicted = True
             if evicted:
+                gc.collect()                  # (a plan holds closures over itself: the cycle collector frees its tensors)
                 torch.cuda.empty_cache()
             while True:
                 try:
@@ -213,6 +215,7 @@ class Darknet(nn.Module):
                     if not self._plans:
                         raise
                     self._plans.popitem(last=False)
+                    gc.collect()
                     torch.cuda.empty_cache()
             # forward buffers now, gradient buffers of about the same size on the first backward
             # (counted from the plan's own tensors: an allocator delta is wrong whenever the garbage collector frees another
@@ -226,6 +229,7 @@ class Darknet(nn.Module):
                 self._plans.popitem(last=False)
                 evicted = True
             if evicted:
+                gc.collect()
                 torch.cuda.empty_cache()      # hand the evicted plans' blocks back: the caching allocator would keep them
                                               # reserved next to the new plan's (a 20-shape batch-64 schedule reached 245 GB)
             red = getattr(self, '_reducer', None)

@@ -14,6 +14,7 @@ Backward mirrors it in reverse: ssp_bn_act_bwd (in place over the raw conv outpu
 ssp_unpack_grad, and ssp_conv_dgrad into the producer's gradient buffer (accumulating when a map has two consumers).
 """
 import os
+import weakref
 
 import torch
 
@@ -1425,11 +1426,20 @@ class _DarknetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        plan = ctx.plan
+        plan = ctx.plan if ctx.plan is not None else ctx.plan_ref()
+        if plan is None:
+            raise RuntimeError("Darknet backward called twice on the same forward, and the plan of that input shape has "
+                               "left the plan cache since (another resolution took its memory): run the forward again")
         if plan.generation != ctx.generation:
             raise RuntimeError("Darknet backward after a newer forward on the same input shape: the plan's saved "
                                "activations were overwritten")
         grads = plan.backward(grad_out.contiguous())
+        # Until its backward has run the node keeps its plan alive (forward at shape A, forward at shape B, backward of A
+        # works whatever the cache evicted).  Afterwards only the cache does: a caller that still holds the loss tensor of the
+        # previous resolution (every training loop does, until it assigns the next one) must not keep that resolution's
+        # 30 - 65 GB of buffers next to the new plan's - that pair was the peak of the multi-scale soak.
+        ctx.plan_ref = weakref.ref(plan)
+        ctx.plan = None
         res = [None, None, None]
         for p in ctx.params:
             res.append(grads.get(id(p)))

@@ -161,6 +161,16 @@ if __name__ == '__main__':
 
 
 # ---- parsing what the reference's drivers print (valid.py:205-222, region_loss.py:173) ----
+def add_backgrounds(root, seed=5):
+    """Two more backgrounds of other sizes next to make()'s bg0.png, for callers that list the directory SORTED
+    (tools/dump_dataset_epoch.py; train.py's os.listdir order is file-system dependent, so make() itself keeps one)."""
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    d = os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages')
+    for name, (h, w) in (('bg1.png', (300, 400)), ('bg2.png', (500, 333))):
+        Image.fromarray(_texture(rs, h, w)).save(os.path.join(d, name))
+
+
 def parse_valid_output(text):
     import re
     out = {}

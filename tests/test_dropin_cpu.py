@@ -97,3 +97,133 @@ def test_array_shim_honours_numpy2_copy_semantics():
         "print('ok')\n") % os.path.join(ROOT, 'dropin')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+# ---- dropin/dataset.py: the host half (draw order, multi-scale schedule, labels, collate), no GPU --------------------------
+def _dropin_dataset():
+    """(module, cleanup): dropin's `dataset` (and the `utils` / torchvision shims it resolves) imported from dropin/."""
+    d = os.path.join(ROOT, 'dropin')
+    sys.path.insert(0, d)
+    for k in ('dataset', 'utils', 'image'):
+        sys.modules.pop(k, None)
+    import dataset
+
+    def cleanup():
+        sys.path.remove(d)
+        for k in [k for k in sys.modules if k in ('dataset', 'utils', 'image', '_compat', 'torchvision') or k.startswith('torchvision.')]:
+            del sys.modules[k]
+    return dataset, cleanup
+
+
+def _epoch_batches(dataset, root, seed, seen, epochs, workers=0, batch=8):
+    import random
+    from torchvision import transforms
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        bgdir = os.path.join('VOCdevkit', 'VOC2012', 'JPEGImages')
+        bgs = [os.path.join(bgdir, f) for f in sorted(os.listdir(bgdir))]
+        out = []
+        for _ in range(epochs):
+            loader = torch.utils.data.DataLoader(
+                dataset.listDataset(os.path.join('LINEMOD', 'ape', 'train.txt'), shape=(416, 416), shuffle=True,
+                                    transform=transforms.Compose([transforms.ToTensor(), ]), train=True, seen=seen,
+                                    batch_size=batch, num_workers=workers, bg_file_names=bgs),
+                batch_size=batch, shuffle=False, num_workers=workers)
+            for data, target in loader:
+                out.append((data, target))
+                seen += len(data)
+        return out
+    finally:
+        os.chdir(cwd)
+
+
+def test_dropin_dataset_draws_shapes_and_labels_of_the_reference(tmp_path):
+    """The reference's own dataset.listDataset over the same seeded epochs (oracle/gen_dataset_golden.py): the network shape
+    of every batch (multi-scale schedule, dataset.py:66-90) and every label value, bit for bit - they depend on the shuffle,
+    the shape / background draws and the four jitter draws of every sample, i.e. on the whole draw order."""
+    gold = json.load(open(os.path.join(GOLD, 'dataset_epochs.json')))
+    root = str(tmp_path / 'fixture')
+    fx.make(root)
+    fx.add_backgrounds(root)
+    dataset, cleanup = _dropin_dataset()
+    try:
+        for name in ('fixed_416', 'multiscale_stage1', 'multiscale_last_stage'):
+            g = gold[name]
+            got = _epoch_batches(dataset, root, g['seed'], g['seen'], g['epochs'])
+            assert len(got) == len(g['batches'])
+            for (data, target), gb in zip(got, g['batches']):
+                assert type(data).__name__ == 'RawBatch' and list(data.shape) == gb['shape'] and len(data) == gb['batch']
+                assert data.size() == (gb['batch'], gb['shape'][1], gb['shape'][0], 3) and data.size(0) == gb['batch']
+                assert target.dtype == torch.float64 and tuple(target.shape) == (gb['batch'], 50 * 21)
+                rows = target.numpy().reshape(gb['batch'], 50, 21)
+                for s in range(gb['batch']):
+                    want = np.array([[float.fromhex(v) for v in r] for r in gb['labels'][s]]).reshape(-1, 21)
+                    assert np.array_equal(rows[s, :len(want)], want), (name, s)
+                    assert not rows[s, len(want):].any()
+                # what the GPU pass will be handed: decoded bytes and one draw set per sample
+                smp = data.samples[0]
+                assert smp.img.dtype == torch.uint8 and tuple(smp.img.shape) == (480, 640, 3) == tuple(smp.mask.shape)
+                assert set(smp.draws) == {'pleft', 'pright', 'ptop', 'pbot', 'flip', 'dhue', 'dsat', 'dexp'}
+                try:
+                    data.mean()
+                    assert False, "RawBatch must not behave like a tensor before .cuda()"
+                except AttributeError as e:
+                    assert 'cuda()' in str(e)
+    finally:
+        cleanup()
+
+
+def test_dropin_dataset_through_worker_processes_and_eval_branch(tmp_path):
+    """num_workers > 0: default_collate runs in the worker (the RawSample registration is inherited) and the RawBatch
+    crosses back with its byte tensors; workers are seeded by the DataLoader, so two runs agree.  train=False: the
+    reference's host branch (dataset.py:108-131) - resized PIL image through the caller's transform, float32 labels."""
+    root = str(tmp_path / 'fixture')
+    fx.make(root, n_train=8, n_test=2, batch=4)
+    fx.add_backgrounds(root)
+    dataset, cleanup = _dropin_dataset()
+    try:
+        a = _epoch_batches(dataset, root, 3, 80, 1, workers=2, batch=4)
+        b = _epoch_batches(dataset, root, 3, 80, 1, workers=2, batch=4)
+        assert len(a) == len(b) == 2
+        for (da, ta), (db, tb) in zip(a, b):
+            assert type(da).__name__ == 'RawBatch' and da.shape == db.shape and torch.equal(ta, tb)
+            assert [s.draws for s in da.samples] == [s.draws for s in db.samples]
+            assert all(torch.equal(x.img, y.img) and torch.equal(x.bg, y.bg) for x, y in zip(da.samples, db.samples))
+        assert dataset.multiscale_width(0, 2, 8) == 13 and dataset.multiscale_width(159, 2, 8) == 13
+
+        class Fixed(object):
+            def __init__(self):
+                self.calls = []
+
+            def randint(self, lo, hi):
+                self.calls.append((lo, hi))
+                return hi
+        for stage, (hi, base) in enumerate([(7, 13), (9, 12), (11, 11), (13, 10), (15, 9), (17, 8), (19, 7), (19, 7), (19, 7)], 1):
+            r = Fixed()
+            assert dataset.multiscale_width(160 * stage, 2, 8, r) == hi + base and r.calls == [(0, hi)]
+        assert dataset.multiscale_width(5, 0, 8, Fixed()) == 26          # fewer samples than one batch: the last branch
+
+        from torchvision import transforms
+        cwd = os.getcwd()
+        os.chdir(root)
+        try:
+            ds = dataset.listDataset('LINEMOD/ape/test.txt', shape=(96, 64), shuffle=False,
+                                     transform=transforms.Compose([transforms.ToTensor(), ]), train=False)
+            img, label = ds[1]
+            from PIL import Image
+            want = transforms.ToTensor()(Image.open('LINEMOD/ape/JPEGImages/000009.png').convert('RGB').resize((96, 64)))
+            assert torch.equal(img, want) and tuple(img.shape) == (3, 64, 96)
+            assert label.dtype == torch.float32 and label.numel() == 50 * 21 and label[1] > 0 and not label[21:].any()
+            try:
+                dataset.listDataset('LINEMOD/ape/train.txt', train=True, transform=lambda x: x, bg_file_names=['x'])
+                assert False
+            except TypeError as e:
+                assert 'ToTensor' in str(e)
+        finally:
+            os.chdir(cwd)
+    finally:
+        cleanup()

@@ -276,6 +276,44 @@ def test_plan_cache_multiscale_revisit_and_eviction():
     assert [k[1] for k in model._plans] == [256, 288]
 
 
+def test_evicted_plan_is_freed_while_the_caller_still_holds_its_loss():
+    """A training loop holds the previous resolution's loss tensor while it runs the next forward.  Before its backward
+    the autograd node keeps its plan (forward A, forward B, backward A works whatever was evicted); after it only the cache
+    does, so an evicted plan's buffers really go back to the allocator (the multi-scale soak's peak was two plans)."""
+    import gc
+    import weakref
+    from singleshotpose_amd.darknet import Darknet
+    torch.manual_seed(0)
+    m = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg')).cuda().train()
+    dev = torch.cuda.current_device()
+    xa, xb = torch.rand(2, 3, 160, 160, device='cuda'), torch.rand(2, 3, 224, 224, device='cuda')
+    loss_a = m(xa).square().sum()
+    loss_a.backward(retain_graph=True)                  # (retain_graph: autograd itself will not stop a second call below)
+    m.zero_grad(set_to_none=True)
+    ref_a = weakref.ref(m._plans[(2, 160, 160, dev)])
+    m._plan_mem_frac = 0.0                              # every new shape evicts everything else
+    pending = m(xa * 0.5).square().sum()                # forward at A again, NOT yet backpropagated ...
+    out_b = m(xb)                                       # ... then shape B evicts A from the cache
+    assert list(m._plans) == [(2, 224, 224, dev)]
+    assert ref_a() is not None                          # pending backward: the node still owns plan A
+    pending.backward()                                  # and it works
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.zero_grad(set_to_none=True)
+    del pending
+    gc.collect()
+    if ref_a() is not None:
+        holders = [type(r).__name__ + ':' + repr(r)[:120] for r in gc.get_referrers(ref_a())]
+        assert False, "plan A outlived its eviction although both backwards had run; held by %s" % holders
+    assert float(loss_a.detach()) == float(loss_a.detach()) and out_b.shape[0] == 2      # loss_a itself is still a valid tensor
+    with pytest.raises(RuntimeError, match='plan'):     # its node has no plan any more
+        loss_a.backward()
+    # and the plain double backward on a cached plan: refused by the plan (the chain rewrites the saved conv outputs in place)
+    l = m(xb).square().sum()
+    l.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='twice'):
+        l.backward()
+
+
 def test_uint8_image_input_equals_totensor_path():
     """Darknet accepts the decoder's uint8 (B,H,W,3) bytes directly: same output, bit for bit, as feeding the
     ToTensor'd NCHW float tensor the reference's loader builds (dataset.py:113-131); training step included."""

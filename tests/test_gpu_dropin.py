@@ -28,15 +28,16 @@ pytestmark = pytest.mark.gpu
 CALLERS = ('valid.py', 'train.py', 'dataset.py', 'image.py', 'MeshPly.py')
 
 
-def _callers_dir(tmp_path):
+def _callers_dir(tmp_path, names=CALLERS, sub='reference_callers'):
     """A directory holding ONLY the driver scripts (and dataset.py / image.py / MeshPly.py): `python <dir>/valid.py`
-    puts <dir> first on sys.path, and darknet / region_loss / utils / cfg must resolve to dropin/, not to the reference."""
+    puts <dir> first on sys.path, and darknet / region_loss / utils / cfg must resolve to dropin/, not to the reference.
+    `names` without dataset.py / image.py: those two resolve to dropin/ as well (the GPU augmentation)."""
     import shutil
-    dst = str(tmp_path / 'reference_callers')
+    dst = str(tmp_path / sub)
     os.makedirs(dst, exist_ok=True)
     ref = '/root/reference'
-    if all(os.path.isfile(os.path.join(ref, n)) for n in CALLERS):
-        for n in CALLERS:
+    if all(os.path.isfile(os.path.join(ref, n)) for n in names):
+        for n in names:
             shutil.copy(os.path.join(ref, n), os.path.join(dst, n))
         return dst
     z = os.path.join(ROOT, 'oracle', '_ref', 'callers.zip')
@@ -44,13 +45,14 @@ def _callers_dir(tmp_path):
         pytest.skip("the reference's driver scripts are not staged (oracle/_ref/callers.zip: run __graft_entry__.build() "
                     "in the build container, where /root/reference exists)")
     with zipfile.ZipFile(z) as f:
-        f.extractall(dst)
+        for n in names:
+            f.extract(n, dst)
     return dst
 
 
-def _run(cmd, cwd, timeout=900):
+def _run(cmd, cwd, timeout=900, first=()):
     env = dict(os.environ)
-    env['PYTHONPATH'] = os.pathsep.join([ROOT, os.path.join(ROOT, 'dropin')])
+    env['PYTHONPATH'] = os.pathsep.join(list(first) + [ROOT, os.path.join(ROOT, 'dropin')])
     env['PYTHONUNBUFFERED'] = '1'
     p = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-4000:]
@@ -85,9 +87,15 @@ def test_unmodified_valid_py_runs_and_matches_the_cpu_reference(tmp_path):
         assert got[k] == gold[k], k
 
 
-def test_unmodified_train_py_runs_and_matches_the_cpu_reference(tmp_path):
+@pytest.mark.parametrize("data_pipeline", ["reference_pillow", "dropin_gpu"])
+def test_unmodified_train_py_runs_and_matches_the_cpu_reference(tmp_path, data_pipeline):
+    """reference_pillow: `import dataset` in train.py finds the reference's dataset.py / image.py (host Pillow pipeline).
+    dropin_gpu: those two files are NOT beside train.py, so `dataset` is dropin/dataset.py - every batch is augmented by
+    DeviceAugmenter on the GPU inside train.py's own `data.cuda()`; same draws, same bytes, hence the same golden numbers."""
     gold = json.load(open(os.path.join(GOLD, 'dropin_train.json')))
-    ref = _callers_dir(tmp_path)
+    ref = _callers_dir(tmp_path) if data_pipeline == 'reference_pillow' else \
+        _callers_dir(tmp_path, ('valid.py', 'train.py', 'MeshPly.py'), 'callers_without_dataset')
+    assert os.path.isfile(os.path.join(ref, 'dataset.py')) == (data_pipeline == 'reference_pillow')
     root = str(tmp_path / 'fixture')
     fx.make(root, max_epochs=2)
     out = _run([sys.executable, os.path.join(ROOT, 'tools', 'run_pinned.py'), os.path.join(ref, 'train.py'), '--datacfg',
@@ -115,3 +123,55 @@ def test_unmodified_train_py_runs_and_matches_the_cpu_reference(tmp_path):
                 assert abs(a[k] - b[k]) <= 3.0 * spread + 0.05 * abs(b[k]), (i, k, a[k], b[k], spread)
         if i == 0:
             assert (a['proposals'], a['recall']) == (b['proposals'], b['recall'])
+
+
+def _digest(z):
+    import hashlib
+    import numpy as np
+    out, i = [], 0
+    while 'u8_%d' % i in z:
+        u8 = np.ascontiguousarray(z['u8_%d' % i])
+        out.append(([int(u8.shape[2]), int(u8.shape[1])], hashlib.sha1(u8.tobytes()).hexdigest()))
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("name", ["fixed_416", "multiscale_stage1", "multiscale_last_stage"])
+def test_dropin_dataset_epoch_is_the_reference_epoch_byte_for_byte(tmp_path, name):
+    """SURVEY.md section 8(f) row 3 as a drop-in: dropin/dataset.py's listDataset inside a DataLoader, `data.cuda()` as in
+    train.py:82-83, over seeded epochs of the fixture (three background sizes; fixed 416 x 416, the first and the last
+    stage of the multi-scale schedule: 256 x 256 ... 736 x 736) - the pixels of every batch are the bytes the reference's
+    dataset.py + image.py produce (SHA-1 per batch from oracle/gen_dataset_golden.py, the reference run in the build
+    container), the labels are equal as float64.  Where the reference's two files are staged the reference pipeline is
+    also run HERE, on this machine's Pillow, and compared array against array."""
+    import numpy as np
+    gold = json.load(open(os.path.join(GOLD, 'dataset_epochs.json')))[name]
+    root = str(tmp_path / 'fixture')
+    fx.make(root)
+    fx.add_backgrounds(root)
+    tool = os.path.join(ROOT, 'tools', 'dump_dataset_epoch.py')
+    args = ['--seed', str(gold['seed']), '--seen', str(gold['seen']), '--epochs', str(gold['epochs'])]
+    out = str(tmp_path / 'dropin.npz')
+    _run([sys.executable, tool, root, out] + args, str(tmp_path))
+    got = np.load(out)
+    assert str(got['module']) == os.path.join(ROOT, 'dropin', 'dataset.py')
+    dig = _digest(got)
+    assert [d[0] for d in dig] == [b['shape'] for b in gold['batches']]
+    assert [d[1] for d in dig] == [b['sha1'] for b in gold['batches']]
+    for i, b in enumerate(gold['batches']):
+        rows = got['lab_%d' % i].reshape(b['batch'], 50, 21)
+        for s in range(b['batch']):
+            want = np.array([[float.fromhex(v) for v in r] for r in b['labels'][s]]).reshape(-1, 21)
+            assert np.array_equal(rows[s, :len(want)], want) and not rows[s, len(want):].any()
+    z = os.path.join(ROOT, 'oracle', '_ref', 'callers.zip')
+    if os.path.isfile(z) or os.path.isdir('/root/reference'):
+        ref = _callers_dir(tmp_path, ('dataset.py', 'image.py'), 'reference_dataset')
+        out_ref = str(tmp_path / 'reference.npz')
+        _run([sys.executable, tool, root, out_ref, '--cpu'] + args, str(tmp_path), first=[ref])
+        want = np.load(out_ref)
+        assert str(want['module']).startswith(ref)
+        for i in range(len(dig)):
+            a, b = got['u8_%d' % i], want['u8_%d' % i]
+            assert a.shape == b.shape and a.dtype == b.dtype
+            assert np.array_equal(a, b), "batch %d: %d of %d bytes differ" % (i, int((a != b).sum()), a.size)
+            assert np.array_equal(got['lab_%d' % i], want['lab_%d' % i])
