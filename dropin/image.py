@@ -40,7 +40,7 @@ def _rgb(pil_or_path):
 
 def distort_image(im, hue, sat, val):
     x = torch.from_numpy(_rgb(im)).cuda()
-    return Image.fromarray(_image.distort_image(x, hue, sat, val).cpu().numpy(), 'RGB')
+    return Image.fromarray(_image.distort_image(x, hue, sat, val).cpu().numpy())
 
 
 def random_distort_image(im, hue, saturation, exposure):
@@ -55,4 +55,4 @@ def load_data_detection(imgpath, shape, jitter, hue, saturation, exposure, bgpat
     maskpath = imgpath.replace('JPEGImages', 'mask').replace('/00', '/').replace('.jpg', '.png')
     out, label = _augmenter().load_data_detection_batch([_rgb(imgpath)], [_rgb(maskpath)], [_rgb(bgpath)], [labpath], shape,
                                                         jitter, hue, saturation, exposure, num_keypoints, max_num_gt)
-    return Image.fromarray(out[0].cpu().numpy(), 'RGB'), label[0].numpy()
+    return Image.fromarray(out[0].cpu().numpy()), label[0].numpy()

@@ -175,3 +175,35 @@ def test_dropin_dataset_epoch_is_the_reference_epoch_byte_for_byte(tmp_path, nam
             assert a.shape == b.shape and a.dtype == b.dtype
             assert np.array_equal(a, b), "batch %d: %d of %d bytes differ" % (i, int((a != b).sum()), a.size)
             assert np.array_equal(got['lab_%d' % i], want['lab_%d' % i])
+
+
+_IMAGE_PROBE = r'''
+import hashlib, random, sys
+import numpy as np
+from torchvision import transforms      # (dropin's shim also restores ImageMath.eval, which Pillow 12 dropped: image.py:116)
+import image
+random.seed(11)
+img, label = image.load_data_detection('LINEMOD/ape/JPEGImages/000003.png', (352, 288), 0.2, 0.1, 1.5, 1.5,
+                                       'VOCdevkit/VOC2012/JPEGImages/bg2.png', 9, 50)
+d = image.distort_image(img, 0.07, 1.3, 0.8)
+print('PROBE', image.__file__, img.size, hashlib.sha1(np.asarray(img.convert('RGB')).tobytes()).hexdigest(),
+      hashlib.sha1(np.asarray(label, dtype=np.float64).tobytes()).hexdigest(),
+      hashlib.sha1(np.asarray(d.convert('RGB')).tobytes()).hexdigest())
+'''
+
+
+def test_dropin_image_module_per_sample_functions_equal_the_reference(tmp_path):
+    """dropin/image.py keeps image.py's per-sample names (PIL in / out) on the GPU kernels: load_data_detection and
+    distort_image give the reference's bytes and labels for the same seed (non-square network shape, a background of
+    another aspect ratio)."""
+    z = os.path.join(ROOT, 'oracle', '_ref', 'callers.zip')
+    if not (os.path.isfile(z) or os.path.isdir('/root/reference')):
+        pytest.skip("the reference's image.py is not staged (oracle/_ref/callers.zip)")
+    root = str(tmp_path / 'fixture')
+    fx.make(root, n_train=4, n_test=1)
+    fx.add_backgrounds(root)
+    ref = _callers_dir(tmp_path, ('image.py',), 'reference_image')
+    a = [l for l in _run([sys.executable, '-c', _IMAGE_PROBE], root).splitlines() if l.startswith('PROBE')][0].split()
+    b = [l for l in _run([sys.executable, '-c', _IMAGE_PROBE], root, first=[ref]).splitlines() if l.startswith('PROBE')][0].split()
+    assert a[1] == os.path.join(ROOT, 'dropin', 'image.py') and b[1].startswith(ref)
+    assert a[2:] == b[2:], (a, b)

@@ -9,7 +9,7 @@ rm -f $SSP_TUNE_CACHE
 REPO=$(pwd)
 timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 python -c "
-import json; d=json.loads(open('gpurun_out/bench_$TAG.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['verified'], d['roofline']['frac'], d['roofline']['gemm_kernels_only'], d['kernel_ms_per_step']); print(json.dumps(d.get('extra'))[:1500]); print(json.dumps(d.get('cpu_baseline'))[:300])"
+import json; d=json.loads(open('gpurun_out/bench_$TAG.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['verified'], d['roofline']['frac'], d['roofline']['launch_units']['frac'], d['kernel_ms_per_step']); print(json.dumps(d.get('extra'))[:1500]); print(json.dumps(d.get('cpu_baseline'))[:300])"
 tail -3 gpurun_out/bench_$TAG.err
 export SSP_TUNE_VERIFY=0
 cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-extras --profile-run > $REPO/gpurun_out/prof_$TAG.log 2>&1
@@ -28,7 +28,9 @@ python -c "
 import json; d=json.load(open('gpurun_out/traffic_$TAG.json')); print(d['_meta'])"
 find gpurun_out/pmc_traffic_$TAG -name "*.csv" -delete
 unset SSP_TUNE_CACHE
+if [ -z "$SSP_EVIDENCE_SKIP_DIRECT_PMC" ]; then
 bash tools/pmc_conv.sh ${TAG}a l2,l4,l9 fwd,dgrad,wgrad "" 0 > gpurun_out/pmc_conv_${TAG}a.txt 2>&1
-bash tools/pmc_conv.sh ${TAG}b l4,l8,l23 fwd,dgrad,wgradw "" 8006413 > gpurun_out/pmc_conv_${TAG}b.txt 2>&1
+fi
+bash tools/pmc_conv.sh ${TAG}b ${SSP_EVIDENCE_WINO_CASES:-l4,l8,l23} fwd,dgrad,wgradw "" 8006413 > gpurun_out/pmc_conv_${TAG}b.txt 2>&1
 find gpurun_out/pmc_${TAG}a gpurun_out/pmc_${TAG}b -name "*.csv" -delete 2>/dev/null
 grep -E "grid=|MFMA pipe busy" gpurun_out/pmc_conv_${TAG}a.txt gpurun_out/pmc_conv_${TAG}b.txt | head -80
