@@ -1173,6 +1173,28 @@ class Plan(object):
             self.grads[ind] = g
         return g
 
+    def _dgrad(self, cs, src, dy_ptr, dy_ld, written, fused_stats, st):
+        """Data gradient of conv block `cs` into the gradient buffer of its input's producer `src` (with the producer's
+        BatchNorm-backward sums folded in where _plan_bn_fusion arranged it)."""
+        call = _lib.call
+        B = self.B
+        gin = self._grad_buf(src, cs.inp)
+        scs = getattr(cs, 'bn_fuse_src', None)
+        dwt = (self._wino_ud(cs, wino_tile(cs.plan_dgrad)).data_ptr() if wino_tile(cs.plan_dgrad)
+               else _ptr(self._dpack, cs.doff))
+        if scs is not None and src not in written:
+            sv = scs.vec
+            call('ssp_conv_dgrad_bnbwd', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W,
+                 cs.coutp, cs.cin, dy_ld, gin.ld, cs.k, cs.plan_dgrad, self.ws.data_ptr(), self.ws_floats,
+                 scs.raw.data_ptr(), scs.ldraw, sv[2].data_ptr(), sv[3].data_ptr(), sv[0].data_ptr(),
+                 sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), scs.bnp[1], st)
+            fused_stats.add(src)
+        else:
+            call('ssp_conv_dgrad', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W, cs.coutp,
+                 cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
+                 self.ws_floats, st)
+        written.add(src)
+
     def backward(self, grad_out):
         """grad_out: (B, C, h, w) NCHW.  Returns {param tensor id: grad tensor}."""
         if self.consumed:
@@ -1252,6 +1274,7 @@ class Plan(object):
                     self._repack_dgrad(cs, main)
         out_grads = {}
         training = self.was_training
+        tail_sched = side is not main and os.environ.get('SSP_TAIL_SCHED', '1') != '0'
         if self.reducer is not None:
             self.reducer.begin(flat)
 
@@ -1290,14 +1313,22 @@ class Plan(object):
                          v[0].data_ptr(), v[1].data_ptr(), cs.slope, cs.first_partial.data_ptr(), B, cs.H, cs.W, st)
                     call('ssp_bn_bwd_finalize', cs.first_partial.data_ptr(), cs.first_groups, cs.cout, cs.M,
                          1 if training else 0, 0, dgam.data_ptr(), dbet.data_ptr(), v[4].data_ptr(), v[5].data_ptr(), st)
-                    side.wait_stream(main)
+                    # The step's tail is a dependency chain: dgrad of the block's consumer -> this reduce -> this filter
+                    # gradient (HBM-bound: it re-reads the 1.4 GB output gradient).  With the tail schedule the consumer's
+                    # filter gradient (MFMA-bound) was held back behind its data gradient and is running on the side
+                    # stream NOW: this pass stays on the main stream and overlaps it, instead of queueing behind it.
+                    fst = st if tail_sched else st2
+                    if not tail_sched:
+                        side.wait_stream(main)
                     gw = gview(cs.conv.weight, False)
                     call('ssp_first_bwd_wgrad', cs.inp.ptr, wptr, g.ptr, g.ld, v[2].data_ptr(), v[3].data_ptr(),
                          v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(), v[5].data_ptr(), cs.slope,
-                         self._gbuf(cs).data_ptr(), B, cs.H, cs.W, st2)
-                    call('ssp_unpack_grad', self._gbuf(cs).data_ptr(), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, st2)
+                         self._gbuf(cs).data_ptr(), B, cs.H, cs.W, fst)
+                    call('ssp_unpack_grad', self._gbuf(cs).data_ptr(), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, fst)
                     out_grads[id(cs.conv.weight)] = gw
                     if self.reducer is not None:
+                        if tail_sched:
+                            side.wait_stream(main)
                         with torch.cuda.stream(side):
                             self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
                     continue
@@ -1336,6 +1367,13 @@ class Plan(object):
                     db = gview(cs.conv.bias)
                     call('ssp_colsum', dy_ptr, dy_ld, cs.M, cs.cout, db.data_ptr(), st)
                     out_grads[id(cs.conv.bias)] = db
+                src = None if cs.first else producer_of(cs.inp)
+                # tail schedule: the consumer of the fused first block (layer 2) runs its data gradient - the head of the
+                # chain that ends the step - BEFORE its filter gradient is released on the side stream
+                owner = None if src is None else (self.convs.get(src - 1) if src in self.fused_pool else self.convs.get(src))
+                defer = tail_sched and owner is not None and owner.first_live
+                if defer:
+                    self._dgrad(cs, src, dy_ptr, dy_ld, written, fused_stats, st)
                 side.wait_stream(main)          # dY(l) (and the zeroed packed-gradient buffer) are ready
                 gw = gview(cs.conv.weight, cs.packed)
                 if cs.packed and getattr(cs, 'wgrad_wino', 0):
@@ -1354,24 +1392,8 @@ class Plan(object):
                 if self.reducer is not None:
                     with torch.cuda.stream(side):   # the all-reduce of a finished bucket is ordered after its wgrads
                         self.reducer.layer_done(flat, cs.grad_lo, cs.grad_hi)
-                if not cs.first:
-                    src = producer_of(cs.inp)
-                    gin = self._grad_buf(src, cs.inp)
-                    scs = getattr(cs, 'bn_fuse_src', None)
-                    dwt = (self._wino_ud(cs, wino_tile(cs.plan_dgrad)).data_ptr() if wino_tile(cs.plan_dgrad)
-                           else _ptr(self._dpack, cs.doff))
-                    if scs is not None and src not in written:
-                        sv = scs.vec
-                        call('ssp_conv_dgrad_bnbwd', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W,
-                             cs.coutp, cs.cin, dy_ld, gin.ld, cs.k, cs.plan_dgrad, self.ws.data_ptr(), self.ws_floats,
-                             scs.raw.data_ptr(), scs.ldraw, sv[2].data_ptr(), sv[3].data_ptr(), sv[0].data_ptr(),
-                             sv[1].data_ptr(), scs.slope, scs.bnp[0].data_ptr(), scs.bnp[1], st)
-                        fused_stats.add(src)
-                    else:
-                        call('ssp_conv_dgrad', dy_ptr, dwt, gin.ptr, B, cs.H, cs.W, cs.coutp,
-                             cs.cin, dy_ld, gin.ld, cs.k, 1 if src in written else 0, cs.plan_dgrad, self.ws.data_ptr(),
-                             self.ws_floats, st)
-                    written.add(src)
+                if not cs.first and not defer:
+                    self._dgrad(cs, src, dy_ptr, dy_ld, written, fused_stats, st)
             elif t == 'maxpool':
                 if ind not in written:
                     continue
