@@ -133,7 +133,8 @@ def test_multi_object_full_trunk_train_step():
 # at the smallest, a mid and the largest training resolution at the cfg's own batch (8), plus one non-416 shape at the
 # metric's batch (64): the same decision-frozen step check and the same bars as the 416 x 416 headline test - tuned plans
 # on (these shapes pick other tiles / splits / hybrid launches / XCD orders than 416 does: 7 x 7 ... 26 x 26 head grids).
-MULTISCALE = [(224, 8), (608, 8), (832, 8), (352, 64)]
+# (288, 7): 9 x 9 head grid - its deepest 3x3 layers tile as 2 x 2 image mosaics, the second one with a phantom image
+MULTISCALE = [(224, 8), (608, 8), (832, 8), (352, 64), (288, 7)]
 
 
 @pytest.mark.parametrize("size,B", MULTISCALE)
