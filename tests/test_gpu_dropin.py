@@ -207,3 +207,48 @@ def test_dropin_image_module_per_sample_functions_equal_the_reference(tmp_path):
     b = [l for l in _run([sys.executable, '-c', _IMAGE_PROBE], root, first=[ref]).splitlines() if l.startswith('PROBE')][0].split()
     assert a[1] == os.path.join(ROOT, 'dropin', 'image.py') and b[1].startswith(ref)
     assert a[2:] == b[2:], (a, b)
+
+
+_BATCH_PROBE = r'''
+import os, random, sys
+import numpy as np, torch
+from torchvision import transforms
+import dataset, image
+random.seed(5); torch.manual_seed(5)
+bgdir = 'VOCdevkit/VOC2012/JPEGImages'
+ds = dataset.listDataset('LINEMOD/ape/train.txt', shape=(416, 416), shuffle=False, transform=transforms.Compose([transforms.ToTensor()]),
+                         train=True, seen=0, batch_size=4, num_workers=0, bg_file_names=[os.path.join(bgdir, f) for f in sorted(os.listdir(bgdir))])
+data, target = next(iter(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0, pin_memory=True)))
+a = data.cuda()
+b = data.to('cuda')
+c = data.to(device=torch.device('cuda', 0))
+assert a.dtype == torch.uint8 and tuple(a.shape) == (4, 416, 416, 3) == data.size() and torch.equal(a, b) and torch.equal(a, c)
+os.environ['SSP_DATASET_FLOAT'] = '1'
+f = data.cuda()
+assert f.dtype == torch.float32 and tuple(f.shape) == (4, 3, 416, 416)
+assert torch.equal(f, a.permute(0, 3, 1, 2).float().div(255))          # ToTensor's layout and arithmetic
+try:
+    data.to('cpu'); raise SystemExit('RawBatch.to(cpu) must refuse')
+except RuntimeError as e:
+    assert 'no CPU fallback' in str(e)
+# image.random_distort_image: the three draws of image.py:39-44, then the GPU distort of the same values
+from PIL import Image
+im = Image.fromarray(a[0].cpu().numpy())
+random.seed(9); got = image.random_distort_image(im, 0.1, 1.5, 1.5)
+random.seed(9); dh = random.uniform(-0.1, 0.1); ds_ = image.rand_scale(1.5); de = image.rand_scale(1.5)
+want = image.distort_image(im, dh, ds_, de)
+assert np.array_equal(np.asarray(got), np.asarray(want))
+from singleshotpose_amd.darknet import Darknet
+print('PROBE_OK', float(a.float().mean()))
+'''
+
+
+def test_rawbatch_device_entry_points_and_float_mode(tmp_path):
+    """RawBatch.cuda() / .to('cuda') / .to(device=...) give the same uint8 batch; SSP_DATASET_FLOAT=1 returns ToTensor's own
+    (B, 3, H, W) float batch of the same bytes; .to('cpu') refuses; dropin image.random_distort_image draws in image.py's
+    order."""
+    root = str(tmp_path / 'fixture')
+    fx.make(root, n_train=4, n_test=1, batch=4)
+    fx.add_backgrounds(root)
+    out = _run([sys.executable, '-c', _BATCH_PROBE], root)
+    assert 'PROBE_OK' in out, out[-2000:]
