@@ -182,7 +182,7 @@ class listDataset(Dataset):
         return self.nSamples
 
     def __getitem__(self, index):
-        assert index <= len(self), 'index range error'
+        assert index <= len(self), 'index range error'      # (dataset.py:57 has <=, kept: index == len raises IndexError below)
         imgpath = self.lines[index].rstrip()
         if self.train and index % self.batch_size == 0:
             width = multiscale_width(self.seen, self.nbatches, self.batch_size) * self.cell_size
