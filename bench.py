@@ -231,6 +231,17 @@ def verify_step(model, crit, B, H, W, seed, exact=False):
     if exact:
         ok = ok and all(a <= max(1e-4, 3.0 * b) for a, b in r['grad64_by_param'].values())
     det = {k: float('%.3g' % r[k]) for k in list(bars) + (['grad64', 'grad64_ref'] if exact else [])}
+    # margin = bar / error per quantity (how much headroom each parity bar has on this batch with this box's plan set), the
+    # parameter gradients split into the first layer's filter (bar 5e-4, see above) and every other parameter (bar 1e-4)
+    others = {n: e for n, e in r['grad_by_param'].items() if n != '0.weight'}
+    worst = sorted(others.items(), key=lambda kv: -kv[1])[:3]
+    det['grad_other_params'] = float('%.3g' % max(others.values()))
+    det['grad_first_filter'] = float('%.3g' % r['grad_by_param'].get('0.weight', 0.0))
+    det['margin'] = {k: round(bars[k] / max(r[k], 1e-30), 1) for k in ('head', 'loss', 'running', 'conv', 'grad_out')}
+    det['margin']['grad_other_params'] = round(1e-4 / max(det['grad_other_params'], 1e-30), 1)
+    det['margin']['grad_first_filter'] = round(5e-4 / max(det['grad_first_filter'], 1e-30), 1)
+    det['worst_grad_params'] = [[n, float('%.3g' % e)] for n, e in worst]
+    det['conv_worst_layer'] = max(r['conv_by_layer'].items(), key=lambda kv: kv[1])[0] if r.get('conv_by_layer') else None
     det.update(bars={k: v for k, v in bars.items()}, seconds=round(time.time() - t0, 1),
                tuned_plans=sum(1 for _, f, d in r['plans'] if f or d),
                what="1 train step, batch %d, %dx%d, vs oracle/step_check.py (CPU, reference semantics)" % (B, H, W))

@@ -35,6 +35,16 @@ __device__ __forceinline__ void ssp_wait_vmcnt() {
 #endif
 }
 
+// One accumulation group of the K loop: FLN unrolled ring revolutions of NS chunks; the very first chunk is FRESH
+template <int FLN, int NS, typename Step, int... Is>
+__device__ __forceinline__ void ssp_sfor_groups_impl(Step& step, std::integer_sequence<int, Is...>) {
+  (step(std::integral_constant<int, Is % NS>{}, std::integral_constant<bool, Is == 0>{}), ...);
+}
+template <int FLN, int NS, typename Step>
+__device__ __forceinline__ void ssp_sfor_groups(Step& step) {
+  ssp_sfor_groups_impl<FLN, NS>(step, std::make_integer_sequence<int, FLN * NS>{});
+}
+
 // PASS (0 = forward, 1 = data gradient) does not change the code: it gives the two uses distinct kernel names, so a
 // profile can tell the forward launches (exclusive on the GPU) from the dgrad launches (which overlap wgrad on a
 // second stream in Plan.backward).
@@ -48,8 +58,19 @@ __device__ __forceinline__ void ssp_wait_vmcnt() {
 // with one workgroup per CU nothing else hides it.  A chunk has to land only when its slot is about to be read, so the
 // per-step wait leaves NSLOT-3 chunks outstanding: 7 chunks run ahead of the MFMAs instead of 3 (the 4-slot ring's
 // wait - everything but the newest chunk - is the NSLOT = 4 case of the same rule).
-template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
-__global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN < 256) ? 3 : 2)) conv_igemm_dma_kernel(ConvArgs p) {
+//
+// FL > 0 = CHUNKED ACCUMULATION: the fp32 MFMA adds every product into one running sum per output, a chain of K
+// roundings whose error grows like sqrt(K) relative to the partial sums - and in the batched GEMMs of a Winograd plan
+// those partial sums are 3-4 x the size of the final output (the inverse transform cancels them), which is where F(4x4)'s
+// error came from (tools/wino_error_budget.py: rounding V and U to fp32 costs 5e-8 of the output range, the accumulation
+// chain 4e-7 at K = 256 and 9e-7 at K = 1024).  With FL set the K loop runs in groups of FL ring revolutions (8 chunks =
+// K 128 on the 4-slot ring, 9 = K 144 on the 3-slot ring): the first MFMA of a group starts from the inline constant 0
+// instead of the accumulator, and the finished group sum is added to a second register set - two short chains (K 128,
+// then K / 128 group sums) instead of one long one: 2.6 x less error on a K = 1024 F(4x4) plane, 6.6 x on a direct 3x3
+// layer (same simulation), for TM * TN * 16 VALU adds per group (~1.5 % of the group's MFMA time).
+template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2, int FL = 0>
+__global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((FL > 0 && BM + BN >= 256) ? 2 : ((NSLOT == 3 || BM + BN < 256) ? 3 : 2)))
+conv_igemm_dma_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins and gfx950 asm exist in the device pass only
   constexpr int BK = 16, NT = 256;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -224,14 +245,19 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+  // FRESH: the first k-step of an accumulation group takes C = 0 (an inline constant of the MFMA: no register is cleared)
+  auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], auto fresh_tag) {
+    constexpr bool FRESH = decltype(fresh_tag)::value;
+    constexpr f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if (FRESH && e == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], zero16, 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
   };
 
   // ---- prologue: the first NSLOT-1 chunks in flight, wait for all, publish ----
@@ -253,7 +279,7 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // one K chunk; S = ring slot of the chunk being multiplied (compile time: LDS addresses become immediates)
-  auto step = [&](auto slot_tag) {
+  auto step = [&](auto slot_tag, auto fresh_tag) {
     constexpr int S = decltype(slot_tag)::value;
     constexpr int S1 = (S + 1) % NSLOT, SL = (S + NSLOT - 1) % NSLOT;
     constexpr int P = (NSLOT != 3) ? (S & 1) : 0;
@@ -261,8 +287,8 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
     read_frag(S * SLOTB, 1, fa1, fb1);
     if constexpr (NSLOT != 3) read_frag(S1 * SLOTB, 0, fa0[P ^ 1], fb0[P ^ 1]);   // published by the previous barrier
     __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads up here (the scheduler would sink them to their use)
-    mma(fa0[P], fb0[P]);
-    mma(fa1, fb1);
+    mma(fa0[P], fb0[P], fresh_tag);
+    mma(fa1, fb1, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);       // ... and the wait + barrier below the MFMAs (MFMAs are register-only, so
                                              // the scheduler is otherwise free to hoist the barrier above them)
     // the chunk issued one step ago must have landed before it is published; this step's LPW loads stay in flight
@@ -278,43 +304,74 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
     if constexpr (NSLOT == 3) read_frag(S1 * SLOTB, 0, fa0[0], fb0[0]);
   };
   int it = 0;
+  [[maybe_unused]] f32x16 tot[TM][TN];
+  if constexpr (FL > 0) {
+    static_assert(NSLOT == 3 || NSLOT == 4, "chunked accumulation: throughput forms only");
+    constexpr int G = FL * NSLOT;              // chunks per accumulation group
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    for (; it + G <= niter; it += G) {
+      ssp_sfor_groups<FL, NSLOT>(step);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
+    }
+    // the remaining chunks (fewer than a group) start from a cleared accumulator and are added below
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
   if constexpr (NSLOT == 8) {
     for (; it + 8 <= niter; it += 8) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
-      step(std::integral_constant<int, 4>{});
-      step(std::integral_constant<int, 5>{});
-      step(std::integral_constant<int, 6>{});
-      step(std::integral_constant<int, 7>{});
+      step(std::integral_constant<int, 0>{}, std::false_type{});
+      step(std::integral_constant<int, 1>{}, std::false_type{});
+      step(std::integral_constant<int, 2>{}, std::false_type{});
+      step(std::integral_constant<int, 3>{}, std::false_type{});
+      step(std::integral_constant<int, 4>{}, std::false_type{});
+      step(std::integral_constant<int, 5>{}, std::false_type{});
+      step(std::integral_constant<int, 6>{}, std::false_type{});
+      step(std::integral_constant<int, 7>{}, std::false_type{});
     }
   } else if constexpr (NSLOT == 4) {
     for (; it + 4 <= niter; it += 4) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 0>{}, std::false_type{});
+      step(std::integral_constant<int, 1>{}, std::false_type{});
+      step(std::integral_constant<int, 2>{}, std::false_type{});
+      step(std::integral_constant<int, 3>{}, std::false_type{});
     }
   } else {
     for (; it + 3 <= niter; it += 3) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 0>{}, std::false_type{});
+      step(std::integral_constant<int, 1>{}, std::false_type{});
+      step(std::integral_constant<int, 2>{}, std::false_type{});
     }
   }
-  if (it < niter) { step(std::integral_constant<int, 0>{}); ++it; }
-  if (it < niter) { step(std::integral_constant<int, 1>{}); ++it; }
+  if (it < niter) { step(std::integral_constant<int, 0>{}, std::false_type{}); ++it; }
+  if (it < niter) { step(std::integral_constant<int, 1>{}, std::false_type{}); ++it; }
   if constexpr (NSLOT == 4 || NSLOT == 8) {
-    if (it < niter) { step(std::integral_constant<int, 2>{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 2>{}, std::false_type{}); ++it; }
   }
   if constexpr (NSLOT == 8) {
-    if (it < niter) { step(std::integral_constant<int, 3>{}); ++it; }
-    if (it < niter) { step(std::integral_constant<int, 4>{}); ++it; }
-    if (it < niter) { step(std::integral_constant<int, 5>{}); ++it; }
-    if (it < niter) { step(std::integral_constant<int, 6>{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 3>{}, std::false_type{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 4>{}, std::false_type{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 5>{}, std::false_type{}); ++it; }
+    if (it < niter) { step(std::integral_constant<int, 6>{}, std::false_type{}); ++it; }
   }
 
+  if constexpr (FL > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
+  }
   // retire the run-ahead DMA before the LDS is reused by the epilogue
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -326,7 +383,7 @@ __global__ void __launch_bounds__(256, NSLOT >= 6 ? 1 : ((NSLOT == 3 || BM + BN 
 #endif
 }
 
-template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2>
+template <int BM, int BN, int PASS, int NSLOT = 4, int WM = 2, int WN = 2, int FL = 0>
 static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
   a.ntile_m = ssp_cdiv(a.M, BM);
   a.ntile_n = ssp_cdiv(a.Cout, BN);
@@ -337,7 +394,7 @@ static int launch_dma(ConvArgs& a, int tail_ks, hipStream_t stream) {
   a.it_per_split = ssp_cdiv(niter_total, a.ksplit);
   a.ksplit = ssp_cdiv(niter_total, a.it_per_split);
   const int lds_bytes = NSLOT * (BM + BN) * 64 + ((BN % 64) ? 1024 : 0);
-  auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT, WM, WN>;
+  auto kern = conv_igemm_dma_kernel<BM, BN, PASS, NSLOT, WM, WN, FL>;
   static SspKernelCache cache;   // per instantiation, per device
   int slots = 0;                 // workgroups resident on the whole chip at once
   if (int rc = ssp_kernel_prepare((const void*)kern, lds_bytes, 256, &cache, &slots, "conv_igemm_dma")) return rc;
@@ -384,6 +441,21 @@ int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int i
     return bm == 64 ? launch_dma<64, 128, 0, 8>(a, tk, stream) : launch_dma<128, 128, 0, 8>(a, tk, stream);
   }
   if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, 0, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, 0, stream);
+  // Chunked accumulation (see the kernel; the "acc_chunk" option, on by default): K loops of at least two accumulation
+  // groups per workgroup - K >= 256 on the 4-slot ring, 288 on the 3-slot ring - i.e. every launch whose chain is long
+  // enough for its rounding to matter; shorter loops run the plain kernel (their whole chain is one group anyway).
+  const int chunks = ssp_cdiv(a.R * a.R * (a.Cin / 16), a.ksplit > 1 ? a.ksplit : 1);
+  const bool fl = ssp_option(SSP_OPT_ACC_CHUNK) != 0 && chunks >= (three ? 18 : 16);
+  if (fl) {
+    if (is_dgrad) {
+      if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 64, 1, 4, 2, 2, 2>(a, tk, stream);
+      if (bm == 64) return three ? launch_dma<64, 128, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<64, 128, 1, 4, 2, 2, 2>(a, tk, stream);
+      return three ? launch_dma<128, 128, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 128, 1, 4, 2, 2, 2>(a, tk, stream);
+    }
+    if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 64, 0, 4, 2, 2, 2>(a, tk, stream);
+    if (bm == 64) return three ? launch_dma<64, 128, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<64, 128, 0, 4, 2, 2, 2>(a, tk, stream);
+    return three ? launch_dma<128, 128, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 128, 0, 4, 2, 2, 2>(a, tk, stream);
+  }
   if (is_dgrad) {
     if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, tk, stream) : launch_dma<128, 64, 1>(a, tk, stream);
     if (bm == 64) return three ? launch_dma<64, 128, 1, 3>(a, tk, stream) : launch_dma<64, 128, 1>(a, tk, stream);

@@ -96,8 +96,8 @@ void ssp_set_error(const char* fmt, ...) {
 }
 
 // ---- tuning knobs ----
-static int g_options[SSP_OPT_COUNT] = {1, 0, 0, 0, 0, 0};
-static const char* g_option_names[SSP_OPT_COUNT] = {"igemm_xcd", "igemm_variant", "wgrad_variant", "igemm_plan", "wgrad_split", "wino_variant"};
+static int g_options[SSP_OPT_COUNT] = {1, 0, 0, 0, 0, 0, 1};
+static const char* g_option_names[SSP_OPT_COUNT] = {"igemm_xcd", "igemm_variant", "wgrad_variant", "igemm_plan", "wgrad_split", "wino_variant", "acc_chunk"};
 int ssp_option(int which) { return g_options[which]; }
 
 // ---- per-device kernel configuration cache ----

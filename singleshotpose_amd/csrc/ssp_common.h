@@ -61,7 +61,7 @@ struct SspProfScope {
 };
 
 // tuning knobs set through ssp_set_option (ssp_api.hip)
-enum SspOption { SSP_OPT_IGEMM_XCD = 0, SSP_OPT_IGEMM_VARIANT = 1, SSP_OPT_WGRAD_VARIANT = 2, SSP_OPT_IGEMM_PLAN = 3, SSP_OPT_WGRAD_SPLIT = 4, SSP_OPT_WINO_VARIANT = 5, SSP_OPT_COUNT = 6 };
+enum SspOption { SSP_OPT_IGEMM_XCD = 0, SSP_OPT_IGEMM_VARIANT = 1, SSP_OPT_WGRAD_VARIANT = 2, SSP_OPT_IGEMM_PLAN = 3, SSP_OPT_WGRAD_SPLIT = 4, SSP_OPT_WINO_VARIANT = 5, SSP_OPT_ACC_CHUNK = 6, SSP_OPT_COUNT = 7 };
 int ssp_option(int which);
 
 // Per-device cache of one kernel instantiation's dynamic-LDS reservation and chip-wide resident-workgroup count

@@ -30,6 +30,10 @@ def main():
     ap.add_argument('--variants', default='', help='comma list: run every case once per igemm_variant value')
     ap.add_argument('--plans', default='0', help='comma list of explicit plan codes for fwd / dgrad (0 = heuristic; 9006413 etc. = '
                                                  'Winograd: filters are transformed first, outside the timed launches)')
+    ap.add_argument('--err', action='store_true', help='also print the forward / data-gradient error of every row against a float64 '
+                                                       'evaluation of 4096 sampled output pixels (rms and max, relative to the output range)')
+    ap.add_argument('--stats', default='unit', choices=['unit', 'net'], help="operand statistics: unit = uniform(-1, 1) everywhere; "
+                    "net = what the network's layers see (leaky(N(0,1)) activations, N(0, 1/sqrt(fan-in)) filters)")
     ap.add_argument('--sweep', default='', help='option sets "name=value,...;name=value,..." (- = defaults): every case once per set, '
                                                 'in one process (options of the previous set are reset to 0)')
     args = ap.parse_args()
@@ -66,17 +70,50 @@ def main():
       run_cases(args, dev, st, B)
 
 
+def err_refs(x, dy, w, wd, B, H, W, Cin, Cout, coutp, R, dev, n=4096):
+    """float64 values of n sampled output pixels of the forward conv (x * w) and of the data gradient (dy * wd): the taps of a
+    pixel are gathered with the zero padding and contracted with the [taps * K][N] filter matrix by a float64 matmul."""
+    M = B * H * W
+    g = torch.Generator(device='cpu').manual_seed(7)
+    rows = torch.randperm(M, generator=g)[:min(n, M)].to(dev)
+    b, yy, xx = rows // (H * W), (rows // W) % H, rows % W
+    pad = R // 2
+
+    def gather(src, K):
+        s = src.view(B, H, W, K).double()
+        cols = []
+        for dy_ in range(R):
+            for dx_ in range(R):
+                y2, x2 = yy + dy_ - pad, xx + dx_ - pad
+                ok = ((y2 >= 0) & (y2 < H) & (x2 >= 0) & (x2 < W)).double().unsqueeze(1)
+                cols.append(s[b, y2.clamp(0, H - 1), x2.clamp(0, W - 1)] * ok)
+        return torch.cat(cols, 1)
+    fw = w.view(Cout, R * R * Cin).double()
+    ref_f = gather(x, Cin) @ fw.t()
+    fd = wd.view(Cin, R * R * coutp).double()
+    ref_d = gather(dy, coutp) @ fd.t()
+    return {'fwd': (rows, ref_f), 'dgrad': (rows, ref_d)}
+
+
 def run_cases(args, dev, st, B):
     for name in args.cases.split(','):
         H, Cin, Cout, R = CASES[name]
         W = H
         M = B * H * W
         g = torch.Generator(device='cpu').manual_seed(1)
-        x = (torch.rand(M * Cin, generator=g) * 2 - 1).to(dev)
         coutp = (Cout + 3) // 4 * 4
-        dy = (torch.rand(M * coutp, generator=g) * 2 - 1).to(dev)
-        w = (torch.rand(Cout * R * R * Cin, generator=g) * 2 - 1).to(dev) * 0.05
-        wd = (torch.rand(Cin * R * R * coutp, generator=g) * 2 - 1).to(dev) * 0.05
+        if args.stats == 'net':
+            x = torch.randn(M * Cin, generator=g)
+            x = torch.where(x > 0, x, 0.1 * x).to(dev)
+            dy = torch.randn(M * coutp, generator=g).to(dev)
+            w = (torch.randn(Cout * R * R * Cin, generator=g) / (R * R * Cin) ** 0.5).to(dev)
+            wd = (torch.randn(Cin * R * R * coutp, generator=g) / (R * R * coutp) ** 0.5).to(dev)
+        else:
+            x = (torch.rand(M * Cin, generator=g) * 2 - 1).to(dev)
+            dy = (torch.rand(M * coutp, generator=g) * 2 - 1).to(dev)
+            w = (torch.rand(Cout * R * R * Cin, generator=g) * 2 - 1).to(dev) * 0.05
+            wd = (torch.rand(Cin * R * R * coutp, generator=g) * 2 - 1).to(dev) * 0.05
+        refs = err_refs(x, dy, w, wd, B, H, W, Cin, Cout, coutp, R, dev) if args.err else None
         out = torch.empty(M * coutp, device=dev)
         dx = torch.empty(M * Cin, device=dev)
         dw = torch.zeros(Cout * R * R * Cin, device=dev)
@@ -128,6 +165,11 @@ def run_cases(args, dev, st, B):
                     ts.append(e0.elapsed_time(e1))
                 med = float(np.median(ts))
                 line += ' %s %7.1f us %6.1f TF |' % (op, med * 1e3, flop / (med * 1e-3) / 1e12)
+                if refs is not None and op in ('fwd', 'dgrad'):
+                    rows, ref = refs[op]
+                    got = (out.view(M, coutp)[rows, :Cout] if op == 'fwd' else dx.view(M, Cin)[rows]).double()
+                    e = (got - ref) / ref.abs().max()
+                    line += ' err rms %.2e max %.2e |' % (float(e.pow(2).mean().sqrt()), float(e.abs().max()))
             print(line, flush=True)
 
 
