@@ -213,6 +213,19 @@ def wino_traffic_per_step():
     return round(tot / steps), src
 
 
+def _budget_record(model):
+    for plan in model._plans.values():
+        hb = getattr(plan, 'head_budget', None)
+        if hb:
+            return {"budget": hb['budget'], "head_deviation_of_the_chosen_plans": float('%.3g' % hb['head_deviation']),
+                    "moved": [{"layer": i, "from": "F(%dx%d)" % (a, a), "to": ("F(%dx%d)" % (b, b)) if b else "direct"} for i, a, b in hb['moved']],
+                    "cost_ms_per_forward": round(hb['cost_ms'], 4),
+                    "per_layer_candidates": {str(i): [{"family": ("F(%dx%d)" % (f, f)) if f else "direct", "plan": c, "ms": t, "head_deviation": d}
+                                                      for f, c, t, d in rows] for i, rows in hb['table'].items()},
+                    "env": "SSP_HEAD_ERR_BUDGET (0 = always the fastest code)"}
+    return None
+
+
 def verify_step(model, crit, B, H, W, seed, exact=False):
     """One training step of THIS model on THIS batch against the CPU oracle (oracle/step_check.py), before anything is
     timed: head / loss / running statistics vs an independent oracle forward, every conv launch vs the oracle's
@@ -230,7 +243,7 @@ def verify_step(model, crit, B, H, W, seed, exact=False):
     # (--verify-exact: adds ~50 s of float64 CPU work; tests/test_gpu_fullsize.py always runs it)
     if exact:
         ok = ok and all(a <= max(1e-4, 3.0 * b) for a, b in r['grad64_by_param'].values())
-    det = {k: float('%.3g' % r[k]) for k in list(bars) + (['grad64', 'grad64_ref'] if exact else [])}
+    det = {k: float('%.3g' % r[k]) for k in list(bars) + (['grad64', 'grad64_ref', 'head64', 'head64_ref'] if exact else [])}
     # margin = bar / error per quantity (how much headroom each parity bar has on this batch with this box's plan set), the
     # parameter gradients split into the first layer's filter (bar 5e-4, see above) and every other parameter (bar 1e-4)
     others = {n: e for n, e in r['grad_by_param'].items() if n != '0.weight'}
@@ -737,6 +750,10 @@ def main():
             "final_loss": final_loss,
             "verified": verified,
             "verify": verify_detail,
+            # error-aware admission of the forward plans (engine.Plan._apply_head_budget): head deviation of every Winograd
+            # candidate measured on the first batch, the layers that were moved to a more accurate family to keep the
+            # budget, and the launch time that cost
+            "head_budget": _budget_record(model),
         }
         if dist_on:
             res["comm"] = comm

@@ -7,6 +7,7 @@ oracle/region_loss_ref.py: the reference's PyTorch-CPU semantics), from the same
 returns the error of every quantity the step produces:
 
   head      max|a-b|/max|b| of the raw network output vs an independent oracle forward     (bar 1e-4)
+  head64 / head64_ref (exact=True)  the product's head and the fp32 oracle's head against an independent FLOAT64 forward
   loss      relative error of the RegionLoss value                                          (bar 1e-4)
   running   worst max-normalised error of the BatchNorm running_mean / running_var updates  (bar 1e-4)
   conv      worst per-layer error of the product's raw conv outputs vs the oracle's convolution of the product's
@@ -177,6 +178,16 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             bn = model.models[ind][1]
             run = max(run, _rel(bn.running_mean.cpu(), e['running_mean']), _rel(bn.running_var.cpu(), e['running_var']))
     res['running'] = run
+    if exact:
+        # float64 yardstick of the FORWARD pass: an independent float64 evaluation of the same network on the same batch, and
+        # against it the product's head ('head64') and the fp32 oracle's own ('head64_ref': PyTorch-CPU float32 sits ~2e-5 of
+        # the head's range from float64 on this network - BatchNorm amplifies every block's rounding on the way down,
+        # tools/head_amplification.py - so 'head', the distance between two fp32 evaluations, cannot go below that)
+        st64 = [None if e is None else {k: v.double() for k, v in e.items()} for e in state0]
+        with torch.no_grad():
+            y64 = forward_ref(model.blocks, st64, x_cpu.double(), training=True)
+        res['head64'], res['head64_ref'] = _rel(out_c, y64), _rel(y_ref, y64)
+        del st64, y64
     if not frozen_backward:
         return res
 
@@ -263,5 +274,5 @@ def exact_frozen_errors(model, state0, st32, x_cpu, raws, grad_head, acts=None, 
 
 
 def summarize(res):
-    keys = [k for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad', 'grad64', 'grad64_ref') if k in res]
+    keys = [k for k in ('head', 'head64', 'head64_ref', 'loss', 'running', 'conv', 'grad_out', 'grad', 'grad64', 'grad64_ref') if k in res]
     return ', '.join('%s %.2e' % (k, res[k]) for k in keys)

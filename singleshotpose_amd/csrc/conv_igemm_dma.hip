@@ -64,7 +64,7 @@ __device__ __forceinline__ void ssp_sfor_groups(Step& step) {
 // those partial sums are 3-4 x the size of the final output (the inverse transform cancels them), which is where F(4x4)'s
 // error came from (tools/wino_error_budget.py: rounding V and U to fp32 costs 5e-8 of the output range, the accumulation
 // chain 4e-7 at K = 256 and 9e-7 at K = 1024).  With FL set the K loop runs in groups of FL ring revolutions (8 chunks =
-// K 128 on the 4-slot ring, 9 = K 144 on the 3-slot ring): the first MFMA of a group starts from the inline constant 0
+// K 128 on the 4-slot ring, 6 = K 96 on the 3-slot ring): the first MFMA of a group starts from the inline constant 0
 // instead of the accumulator, and the finished group sum is added to a second register set - two short chains (K 128,
 // then K / 128 group sums) instead of one long one: 2.6 x less error on a K = 1024 F(4x4) plane, 6.6 x on a direct 3x3
 // layer (same simulation), for TM * TN * 16 VALU adds per group (~1.5 % of the group's MFMA time).
@@ -441,20 +441,23 @@ int ssp_conv_igemm_dma_launch(ConvArgs& a, int bm, int slots, int tail_ks, int i
     return bm == 64 ? launch_dma<64, 128, 0, 8>(a, tk, stream) : launch_dma<128, 128, 0, 8>(a, tk, stream);
   }
   if (a.Cout <= 32) return is_dgrad ? launch_dma<256, 32, 1, 4, 4, 1>(a, 0, stream) : launch_dma<256, 32, 0, 4, 4, 1>(a, 0, stream);
-  // Chunked accumulation (see the kernel; the "acc_chunk" option, on by default): K loops of at least two accumulation
-  // groups per workgroup - K >= 256 on the 4-slot ring, 288 on the 3-slot ring - i.e. every launch whose chain is long
-  // enough for its rounding to matter; shorter loops run the plain kernel (their whole chain is one group anyway).
+  // Chunked accumulation (see the kernel; the "acc_chunk" option, on by default): groups of two ring revolutions - 6 chunks
+  // = K 96 on the 3-slot ring, 8 chunks = K 128 on the 4-slot ring - for every K loop of at least 12 chunks (K >= 192: a
+  // group and a half); shorter loops run the plain kernel (their whole chain is hardly longer than one group).  Measured
+  // (profiles/r05_convbench_acc_chunk.txt, error against float64 on the network's operand statistics): direct 3x3, K =
+  // 9216: rms 1.75e-7 -> 4.0e-8 of the output range, F(4x4) planes of K = 1024: 6.1e-7 -> 2.45e-7 (max 9.5e-6 -> 2.4e-6),
+  // launch times within +-1.5 %.
   const int chunks = ssp_cdiv(a.R * a.R * (a.Cin / 16), a.ksplit > 1 ? a.ksplit : 1);
-  const bool fl = ssp_option(SSP_OPT_ACC_CHUNK) != 0 && chunks >= (three ? 18 : 16);
+  const bool fl = ssp_option(SSP_OPT_ACC_CHUNK) != 0 && chunks >= 12;
   if (fl) {
     if (is_dgrad) {
-      if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 64, 1, 4, 2, 2, 2>(a, tk, stream);
-      if (bm == 64) return three ? launch_dma<64, 128, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<64, 128, 1, 4, 2, 2, 2>(a, tk, stream);
-      return three ? launch_dma<128, 128, 1, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 128, 1, 4, 2, 2, 2>(a, tk, stream);
+      if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3, 2, 2, 2>(a, tk, stream) : launch_dma<128, 64, 1, 4, 2, 2, 2>(a, tk, stream);
+      if (bm == 64) return three ? launch_dma<64, 128, 1, 3, 2, 2, 2>(a, tk, stream) : launch_dma<64, 128, 1, 4, 2, 2, 2>(a, tk, stream);
+      return three ? launch_dma<128, 128, 1, 3, 2, 2, 2>(a, tk, stream) : launch_dma<128, 128, 1, 4, 2, 2, 2>(a, tk, stream);
     }
-    if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 64, 0, 4, 2, 2, 2>(a, tk, stream);
-    if (bm == 64) return three ? launch_dma<64, 128, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<64, 128, 0, 4, 2, 2, 2>(a, tk, stream);
-    return three ? launch_dma<128, 128, 0, 3, 2, 2, 3>(a, tk, stream) : launch_dma<128, 128, 0, 4, 2, 2, 2>(a, tk, stream);
+    if (a.Cout <= 64) return three ? launch_dma<128, 64, 0, 3, 2, 2, 2>(a, tk, stream) : launch_dma<128, 64, 0, 4, 2, 2, 2>(a, tk, stream);
+    if (bm == 64) return three ? launch_dma<64, 128, 0, 3, 2, 2, 2>(a, tk, stream) : launch_dma<64, 128, 0, 4, 2, 2, 2>(a, tk, stream);
+    return three ? launch_dma<128, 128, 0, 3, 2, 2, 2>(a, tk, stream) : launch_dma<128, 128, 0, 4, 2, 2, 2>(a, tk, stream);
   }
   if (is_dgrad) {
     if (a.Cout <= 64) return three ? launch_dma<128, 64, 1, 3>(a, tk, stream) : launch_dma<128, 64, 1>(a, tk, stream);

@@ -30,8 +30,9 @@ def _tune_tag():
     process that had it switched off (SSP_WINOGRAD=0, SSP_WINO_TILES, SSP_WINO_MIN_CHANNELS), must not keep that family
     from ever being timed - and must not hand a Winograd code to a process that switched it off."""
     if os.environ.get('SSP_WINOGRAD', '1') == '0':
-        return 'r4-direct'
-    return 'r4-w%s-c%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'))
+        return 'r5-direct'
+    return 'r5-w%s-c%s-%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'),
+                              os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'))
 
 
 def wino_tile(code):
@@ -47,7 +48,12 @@ _WEIGHTS_EPOCH = [0]
 # autotuned igemm plan per launch shape, shared by every Plan of the process: multi-scale training (dataset.py:66-90
 # draws a new resolution every 10 batches) revisits the same ~20 shapes, each is timed once
 _TUNE_CACHE = {}
-_TUNE_VERIFIED = {}            # launch shape -> the plan code that passed verify-after-tune in this process
+# ... and per FAMILY of that launch (0 = direct kernels, 2 / 4 = Winograd F(2x2) / F(4x4)): launch shape -> {family: (fastest code
+# of the family, its time in ms)} - what the error budget of the forward plans chooses from (Plan._apply_head_budget)
+_TUNE_FAMILY = {}
+_HEAD_BUDGET_CACHE = {}        # (plan shape, tag, budget) -> {layer: forward plan code}: a rebuilt plan re-measures nothing
+_TUNE_VERIFIED = {}            # launch shape -> the plan code(s) that passed verify-after-tune in this process
+_TUNE_VERIFIED_ALSO = set()    # (launch shape, code) pairs verified besides the chosen one (the other families' fastest codes)
 TUNE_REJECTED = []             # (shape key, plan code) pairs verify-after-tune refused
 _TUNE_CACHE_FILE = [None]      # SSP_TUNE_CACHE=<json file>: loaded once, rewritten whenever a new shape was timed
 
@@ -61,7 +67,10 @@ def _tune_cache_load():
         import json
         with open(path) as f:
             for k, v in json.load(f).items():
-                _TUNE_CACHE.setdefault(tuple(json.loads(k)), int(v))
+                if k.startswith('fam|'):
+                    _TUNE_FAMILY.setdefault(tuple(json.loads(k[4:])), {int(f_): (int(c), t) for f_, (c, t) in v.items()})
+                else:
+                    _TUNE_CACHE.setdefault(tuple(json.loads(k)), int(v))
 
 
 def _tune_cache_save():
@@ -70,7 +79,9 @@ def _tune_cache_save():
         import json
         tmp = path + '.tmp.%d' % os.getpid()
         with open(tmp, 'w') as f:
-            json.dump({json.dumps(list(k)): v for k, v in _TUNE_CACHE.items()}, f, indent=0, sort_keys=True)
+            out = {json.dumps(list(k)): v for k, v in _TUNE_CACHE.items()}
+            out.update({'fam|' + json.dumps(list(k)): {str(f_): [c, t] for f_, (c, t) in v.items()} for k, v in _TUNE_FAMILY.items()})
+            json.dump(out, f, indent=0, sort_keys=True)
         os.replace(tmp, path)
 
 
@@ -311,10 +322,6 @@ class Plan(object):
         # statistics / split-K workspaces follow the (tuned or heuristic) plan of each launch
         for cs in self.convs.values():
             M = cs.M
-            # (tile_m = 0 for a Winograd plan: statistics per group of tiles with the groups' pixel counts behind the pairs)
-            cs.tile_m = _lib.query('ssp_conv_stats_tile_m', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
-            cs.ws_fwd = _lib.query('ssp_conv_workspace_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
-            cs.ntile = _lib.query('ssp_conv_stats_tiles', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             # First block in training mode: conv + BN + leaky + pool with the convolution recomputed by every pass
             # instead of stored (csrc/conv_first.hip): the 32-channel full-resolution map (1.42 GB at batch 64, the
             # largest tensor of the net, written and re-read five times by the generic path) never exists.
@@ -323,17 +330,17 @@ class Plan(object):
                                   (M // 4) * cs.out.ld * 4 < (1 << 31) and device.type == 'cuda' and
                                   os.environ.get('SSP_FIRST_FUSED', '1') != '0')
             cs.first_live = False        # the last forward took the fused path (its backward must as well)
-            nstat = _lib.query('ssp_conv_stats_floats', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd)
             if cs.first_fused:
                 cs.first_groups = _lib.query('ssp_first_groups', B, cs.H, cs.W)
                 cs.first_tile = _lib.query('ssp_first_tile_pixels')
-                nstat = max(nstat, cs.first_groups * 64)
                 cs.first_partial = torch.empty(cs.first_groups * 64, **f32)
-            if cs.bn:
-                cs.stats = torch.empty(nstat, **f32)
+            self._size_layer(cs)
         # split-K partial tiles (13x13 layers): one scratch buffer shared by every conv launch of the plan
         self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
+        self._head_budget_done = False
+        self.head_budget = None      # record of Plan._apply_head_budget (what was measured, what was chosen)
+        self.bn_momentum = BN_MOMENTUM
         self.wversion = {}
         self.wino_version = {}
         self.bnversion = {}
@@ -370,6 +377,123 @@ class Plan(object):
         self._sg_failed = False
         self._sg_fwd_live = False
         self._sg_serial = False      # SSP_STEP_GRAPH=2: the captured chains run on one stream
+
+    def _size_layer(self, cs):
+        """Statistics / split-K bookkeeping of one conv block for its CURRENT forward plan code (after tuning, and again
+        when the error budget moves the layer to another family): tile height of the per-tile BatchNorm partials (0 = the
+        counted format of a Winograd launch), their count, the launch's workspace need; the statistics buffer is sized
+        for the largest format any timed family of the layer uses, so a plan change never re-allocates it."""
+        B = self.B
+        q = lambda name, code: _lib.query(name, B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, code)
+        cs.tile_m = q('ssp_conv_stats_tile_m', cs.plan_fwd)
+        cs.ws_fwd = q('ssp_conv_workspace_floats', cs.plan_fwd)
+        cs.ntile = q('ssp_conv_stats_tiles', cs.plan_fwd)
+        codes = set([cs.plan_fwd, 0] + [c for c, _ in (getattr(cs, 'fwd_fams', None) or {}).values()])
+        nstat = max(q('ssp_conv_stats_floats', c) for c in codes)
+        if getattr(cs, 'first_fused', False):
+            nstat = max(nstat, cs.first_groups * 64)
+        if cs.bn and (getattr(cs, 'stats', None) is None or cs.stats.numel() < nstat):
+            cs.stats = torch.empty(nstat, dtype=torch.float32, device=self.device)
+
+    def _apply_head_budget(self):
+        """Error-aware admission of the forward plans: a NETWORK-level rounding budget, measured on the live batch.
+
+        A Winograd F(4x4) launch carries ~2.5e-7 (rms, of the output's range) of rounding that no summation order removes
+        - every M = sum_c U.V element is ONE fp32 number 3-4 x the size of the output it is cancelled into
+        (tools/wino_error_budget.py) - against 4e-8 for the direct kernel with chunked accumulation and ~1e-7 for F(2x2).
+        What that costs at the network output depends on WHERE the layer sits: BatchNorm re-normalises every block, so a
+        perturbation of an early block's output is amplified layer after layer (measured in float64 on the CPU,
+        tools/head_amplification.py: white noise of 1e-6 of the range on layer 4's raw output moves the head by 1.7e-4 of its
+        range, on layer 23's by 6e-6) - F(4x4) on the 104 x 104 and 52 x 52 layers IS the head error of the step (6e-5 of
+        the 1e-4 bar), F(4x4) on the 13 x 13 layers, where it saves the most time, costs nothing measurable.
+
+        So, once per plan, on the first training batch: one forward with every eligible layer on its fastest DIRECT code
+        gives the reference head; then, layer by layer, one forward with that layer alone on its Winograd candidate
+        gives d_l = max|head - reference| / max|reference| - the head deviation that candidate is responsible for, on the
+        live operands and weights.  The deviations of different layers are independent roundings: they add in quadrature.
+        Starting from the fastest code everywhere, the layer with the largest (d^2 saved per millisecond lost) is moved to
+        its next more accurate family (F(4x4) -> F(2x2) -> direct) until sqrt(sum d_l^2) <= SSP_HEAD_ERR_BUDGET (default
+        3.5e-5 of the head's range; 0 = off: always the fastest code).  BatchNorm running statistics are not touched by the
+        measurement forwards (momentum 0).  The record is kept in `plan.head_budget` (bench.py prints it)"""
+        self._head_budget_done = True
+        budget = float(os.environ.get('SSP_HEAD_ERR_BUDGET', '3.5e-5'))
+        if budget <= 0 or not self._tune:
+            return
+        cand = [cs for cs in self.convs.values() if wino_tile(cs.plan_fwd) and 0 in (getattr(cs, 'fwd_fams', None) or {})]
+        if not cand:
+            return
+        ckey = (self.B, self.H, self.W, _tune_tag(), budget, id(self.net))
+        rec = _HEAD_BUDGET_CACHE.get(ckey)
+        if rec is None:
+            o = self.out_act
+            head = lambda: o.t[o.off:o.off + self.B * o.H * o.W * o.ld].clone()
+            fastest = {cs.ind: cs.plan_fwd for cs in cand}
+
+            def run(assign):
+                for cs in cand:
+                    cs.plan_fwd = assign[cs.ind]
+                    self._size_layer(cs)
+                self._fit_workspace()
+                self._forward_body(True, False, False)
+                return head()
+            mom, self.bn_momentum = self.bn_momentum, 0.0
+            try:
+                direct = {cs.ind: cs.fwd_fams[0][0] for cs in cand}
+                ref = run(direct)
+                den = max(float(ref.abs().max()), 1e-30)
+                table = {}         # layer -> [(family, code, ms, deviation)], fastest first; the direct entry has deviation 0
+                for cs in cand:
+                    rows = []
+                    for f_, (c_, t_) in cs.fwd_fams.items():
+                        if f_ == 0:
+                            rows.append((0, c_, t_, 0.0))
+                            continue
+                        if t_ is not None and cs.fwd_fams[0][1] is not None and t_ >= cs.fwd_fams[0][1]:
+                            continue      # slower than the direct code: never an option
+                        d = float((run(dict(direct, **{cs.ind: c_})) - ref).abs().max()) / den
+                        rows.append((f_, c_, t_, d))
+                    rows.sort(key=lambda r: (r[2] if r[2] is not None else 0.0))
+                    table[cs.ind] = rows
+            finally:
+                self.bn_momentum = mom
+            choice = {ind: 0 for ind in table}          # index into table[ind]
+            total = lambda: sum(table[i][choice[i]][3] ** 2 for i in table) ** 0.5
+            moved = []
+            while total() > budget:
+                best, gain = None, 0.0
+                for i, rows in table.items():
+                    k = choice[i]
+                    for k2 in range(k + 1, len(rows)):
+                        if rows[k2][3] < rows[k][3]:
+                            dt = max((rows[k2][2] or 0.0) - (rows[k][2] or 0.0), 1e-6)
+                            g = (rows[k][3] ** 2 - rows[k2][3] ** 2) / dt
+                            if g > gain:
+                                best, gain = (i, k2), g
+                            break
+                if best is None:
+                    break
+                moved.append((best[0], table[best[0]][choice[best[0]]][0], table[best[0]][best[1]][0]))
+                choice[best[0]] = best[1]
+            rec = dict(budget=budget, head_deviation=total(), fastest=fastest,
+                       chosen={i: table[i][choice[i]][1] for i in table},
+                       cost_ms=sum((table[i][choice[i]][2] or 0.0) - (table[i][0][2] or 0.0) for i in table),
+                       moved=moved, table={i: [(f_, c_, None if t_ is None else round(t_, 4), float('%.3g' % d))
+                                               for f_, c_, t_, d in rows] for i, rows in table.items()})
+            _HEAD_BUDGET_CACHE[ckey] = rec
+        for cs in cand:
+            cs.plan_fwd = rec['chosen'].get(cs.ind, cs.plan_fwd)
+            self._size_layer(cs)
+            cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
+        self._fit_workspace()
+        self.head_budget = rec
+
+    def _fit_workspace(self):
+        need = max([1] + [cs.ws_fwd for cs in self.convs.values()] + [getattr(cs, 'ws_dgrad', 0) for cs in self.convs.values()])
+        if need > self.ws_floats:
+            torch.cuda.current_stream().synchronize()      # nothing in flight may still use the old workspace
+            self.ws_floats = need
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._graph = None          # a captured inference chain holds the old workspace pointer
 
     def footprint(self):
         """Bytes of device memory this plan's forward buffers hold or will hold after a training-mode forward (each storage
@@ -684,7 +808,7 @@ class Plan(object):
             bases = []
             if 2 in wino_tiles and min(cs.cin, cs.cout) >= wino_min:
                 bases.append(WINO)
-            if 4 in wino_tiles and min(cs.cin, cs.cout) >= 64:
+            if 4 in wino_tiles and min(cs.cin, cs.cout) >= int(os.environ.get('SSP_WINO4_MIN_CHANNELS', '64')):
                 bases.append(WINO4)
             return tuple(bases)
 
@@ -724,6 +848,7 @@ class Plan(object):
                 keep = False             # a cached Winograd choice whose family is switched off in this process: time the
                                          # other plans, leave the cache entry alone
             best, best_t = 0, None
+            fams = {}                    # family (0 direct, 2 / 4 Winograd tile) -> (fastest code, ms)
             # small-batch inference (valid.py runs B = 1): a few dozen tiles cannot stream the filters at HBM speed;
             # deep K splits put every CU on the weight stream
             deep = tuple(bm * 100 + ks * 10 + sl for bm in (64, 128) for ks in (4, 5, 6, 8, 9) for sl in (3, 4, 8)) \
@@ -748,14 +873,18 @@ class Plan(object):
                 t = min(ts)
                 if best_t is None or t < best_t * 0.985:     # prefer earlier (simpler) candidates on near-ties
                     best, best_t = code, t
+                f_ = wino_tile(code)
+                if f_ not in fams or t < fams[f_][1] * 0.985:
+                    fams[f_] = (code, t)
             if keep:
                 _TUNE_CACHE[key] = best
+                _TUNE_FAMILY[key] = fams
             return best
 
-        def admitted(code, key, launch, out_of, operands, bn_of=None, prep=None):
+        def admitted(code, key, launch, out_of, operands, bn_of=None, prep=None, primary=True):
             """verify-after-tune (see the docstring): code's result against plan 0's on seeded random operands.  A Winograd
             plan is another ALGORITHM, not another summation order: its bar is 3e-5 of the output's range (measured ~1e-6)."""
-            if code == 0 or not verify or _TUNE_VERIFIED.get(key) == code:
+            if code == 0 or not verify or _TUNE_VERIFIED.get(key) == code or (key, code) in _TUNE_VERIFIED_ALSO:
                 return code
             # Operands are the plan's own buffers (they hold no data yet: tuning runs before the first forward, and
             # Plan.backward's fallback never tunes).  Only the columns a launch owns are randomised: the channel padding of
@@ -779,10 +908,14 @@ class Plan(object):
                 if not (err <= bar * max(den, 1e-30)):      # also false for NaN
                     ok = False
             if ok:
-                _TUNE_VERIFIED[key] = code
+                if primary:
+                    _TUNE_VERIFIED[key] = code
+                else:
+                    _TUNE_VERIFIED_ALSO.add((key, code))
                 return code
             TUNE_REJECTED.append((key, code))
-            _TUNE_CACHE[key] = 0
+            if primary:
+                _TUNE_CACHE[key] = 0
             import warnings
             warnings.warn("singleshotpose_amd: verify-after-tune refused plan %d for launch %s (result differs from the "
                           "default plan's); the default plan runs" % (code, key))
@@ -823,9 +956,19 @@ class Plan(object):
                         prep_f(t)
                 code = best_of(launch, cs.M * cs.coutp, key, wc)
                 a = cs.inp
-                cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, [(a.t, a.ld, a.off % a.ld, cs.cinp)] +
-                                       ([] if wop is cs.conv.weight else [wop]), bn_of if cs.bn else None,
+                ops_ = [(a.t, a.ld, a.off % a.ld, cs.cinp)] + ([] if wop is cs.conv.weight else [wop])
+                cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, ops_, bn_of if cs.bn else None,
                                        (lambda code=code: prep_f(wino_tile(code))) if wino_tile(code) else None)
+                # The fastest code of every OTHER family that was timed (direct / F(2x2) / F(4x4)), verified the same way: what
+                # the error budget of the forward plans may fall back to (_apply_head_budget); a refused one is dropped.
+                cs.fwd_fams = {}
+                for f_, (c_, t_) in (_TUNE_FAMILY.get(key) or {}).items():
+                    if c_ == cs.plan_fwd:
+                        cs.fwd_fams[f_] = (c_, t_)
+                    elif c_ != code and admitted(c_, key, launch, lambda cs=cs: cs.raw, ops_, bn_of if cs.bn else None,
+                                                 (lambda c_=c_: prep_f(wino_tile(c_))) if wino_tile(c_) else None,
+                                                 primary=False) == c_:
+                        cs.fwd_fams[f_] = (c_, t_)
                 # not chosen: the transformed-filter buffers go back to the allocator
                 cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
             if which == 'dgrad' and not cs.first and cs.coutp % 16 == 0 and (cs.cin > 64 or wino_codes(cs, which)):
@@ -870,6 +1013,8 @@ class Plan(object):
         # Everything between the two layout conversions is a fixed chain of launches on plan-owned buffers: small training
         # steps (the cfg's own batch 8: ~300 launches of a few microseconds each, host-bound) replay it from a hipGraph
         self._sg_fwd_live = False
+        if training and need_grad and not self._head_budget_done:
+            self._apply_head_budget()        # once per plan, on its first training batch (network-level rounding budget)
         if self._step_graph_mode(training, need_grad, inline_repack):
             key = self._sg_key()
             if self._sg_fwd is not None and self._sg_fwd[0] == key:
@@ -1074,7 +1219,7 @@ class Plan(object):
                         call('ssp_first_fwd_stats', cs.inp.ptr, wptr, cs.stats.data_ptr(), B, cs.H, cs.W, st)
                         call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.first_groups, cs.first_tile, cs.M, cs.cout,
                              bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                             bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
+                             bn.running_var.data_ptr(), self.bn_momentum, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
                              v[2].data_ptr(), v[3].data_ptr(), st)
                     call('ssp_first_fwd_apply', cs.inp.ptr, wptr, v[2].data_ptr(), v[3].data_ptr(), cs.slope,
                          cs.out.ptr, cs.out.ld, B, cs.H, cs.W, st)
@@ -1100,7 +1245,7 @@ class Plan(object):
                     bn = cs.bnm
                     call('ssp_bn_fwd_finalize', cs.stats.data_ptr(), cs.ntile, cs.tile_m, cs.M, cs.cout,
                          bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                         bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
+                         bn.running_var.data_ptr(), self.bn_momentum, BN_EPS, v[0].data_ptr(), v[1].data_ptr(),
                          v[2].data_ptr(), v[3].data_ptr(), st)
                 if cs.needs_act:
                     call('ssp_bn_act_fwd', cs.raw.data_ptr(), cs.ldraw, cs.out.ptr, cs.out.ld, v[2].data_ptr(),

@@ -1,0 +1,233 @@
+"""Synthetic OCCLUSION-shaped mini dataset for driving the reference's own multi_obj_pose_estimation/train_multi.py and
+valid_multi.py (TEST INFRASTRUCTURE; the single-object counterpart is tests/fixture_linemod.py, whose helpers it reuses).
+
+`make(root)` writes, deterministically (seeded numpy, PNG = lossless), everything the two unmodified drivers open.  They
+run with cwd = root/multi and reach the data through '../' (train_multi.py:308 '../VOCdevkit/...', image_multi.py:320
+'../LINEMOD/<obj>/train.txt'):
+
+  root/LINEMOD/<obj>/JPEGImages/0000NN.png, mask/00NN.png, labels/0000NN.txt, <obj>.ply, train.txt
+        for benchvise (the OCCLUSION scenes: train_multi.py trains on them) and the seven objects image_multi.py:12-13
+        pastes next to a benchvise image (ape, can, cat, driller, duck, glue, holepuncher); labels: 21 numbers, class first
+  root/LINEMOD/<obj>/test_occlusion.txt, labels_occlusion/0000NN.txt
+        for the six objects valid_multi.py:163-174 evaluates (ape, can, cat, duck, glue, holepuncher): lists of BENCHVISE
+        test images and, per image, this object's label row (dataset_multi.py:76 derives the path from the image name)
+  root/VOCdevkit/VOC2012/JPEGImages/bg0.png
+  root/multi/cfg/occlusion.data, <obj>_occlusion.data, train_occlusion.txt, yolo-pose-multi.cfg (batch / max_epochs set)
+  root/multi/init.weights
+
+The labels_occlusion rows are what makes valid_multi.py's output (ten 'Acc using N px 2D Projection' lines per object)
+say something: with random weights no prediction lands near a true pose, so every line would read 0.00 %.  They are
+therefore derived from what the REFERENCE network predicts for that image and class (computed once, in the build
+container, by oracle/gen_dropin_golden.py and stored in tests/golden/dropin_multi.json) shifted by a per-image offset of
+2 ... 60 pixels: the reference scores a spread of accuracies over the thresholds, and the drop-in reproduces the lines only
+if its predictions are the reference's to well within a pixel.  `make(root, occlusion_labels=None)` (generation, phase 1)
+writes the true projected boxes instead.
+"""
+import os
+
+import numpy as np
+
+import fixture_linemod as fl
+from fixture_linemod import FX, FY, H, ROOT, U0, V0, W
+
+# class ids of the LINEMOD objects in the OCCLUSION label files (13 classes, cfg/yolo-pose-multi.cfg: classes=13)
+CLASS_ID = dict(ape=0, benchvise=1, cam=2, can=3, cat=4, driller=5, duck=6, eggbox=7, glue=8, holepuncher=9, iron=10,
+                lamp=11, phone=12)
+SCENE = 'benchvise'
+PASTED = ('ape', 'can', 'cat', 'driller', 'duck', 'glue', 'holepuncher')      # image_multi.py:12-13 get_add_objs('benchvise')
+VALID = ('ape', 'can', 'cat', 'duck', 'glue', 'holepuncher')                   # valid_multi.py:163-174
+# object half extents (metres), ape-sized to driller-sized
+HALF = dict(benchvise=(0.10, 0.09, 0.10), ape=(0.038, 0.039, 0.046), can=(0.05, 0.09, 0.10), cat=(0.034, 0.064, 0.059),
+            driller=(0.115, 0.038, 0.104), duck=(0.052, 0.039, 0.043), glue=(0.018, 0.039, 0.086), holepuncher=(0.05, 0.054, 0.045))
+# fix_corner_order (utils_multi.py:244-255): corrected[k] = gt[PERM[k]]
+PERM = (0, 1, 3, 5, 7, 2, 4, 6, 8)
+
+
+def _object(rs, half):
+    pts, nrm, col = fl._mesh(rs, 900)
+    return pts / fl.HALF * np.asarray(half), nrm, col
+
+
+def _corners(half):
+    mn, mx = -np.asarray(half), np.asarray(half)
+    return np.array([[(mx if a else mn)[0], (mx if b else mn)[1], (mx if c else mn)[2]]
+                     for a in (0, 1) for b in (0, 1) for c in (0, 1)])
+
+
+def _write_ply(path, pts, nrm, col):
+    with open(path, 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                'property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\n'
+                'property uchar blue\nelement face 4\nproperty list uchar int vertex_indices\nend_header\n' % len(pts))
+        for p, n, c in zip(pts, nrm, col):
+            f.write('%.6f %.6f %.6f %.4f %.4f %.4f %d %d %d\n' % (p[0], p[1], p[2], n[0], n[1], n[2], c[0], c[1], c[2]))
+        for i in range(4):
+            f.write('3 %d %d %d\n' % (3 * i, 3 * i + 1, 3 * i + 2))
+
+
+def _render(img, mask, pts, nrm, col, R, t):
+    uv, z = fl._project(pts, R, t)
+    order = np.argsort(-z)
+    shade = np.clip(0.4 + 0.6 * np.abs(nrm.dot(R.T)[:, 2]), 0, 1)
+    r = max(2, int(round(3.0 / t[2])))
+    for j in order:
+        x, y = int(round(uv[j, 0])), int(round(uv[j, 1]))
+        x0, x1, y0, y1 = max(x - r, 0), min(x + r + 1, W), max(y - r, 0), min(y + r + 1, H)
+        if x0 < x1 and y0 < y1:
+            img[y0:y1, x0:x1] = (col[j] * shade[j]).astype(np.uint8)
+            if mask is not None:
+                mask[y0:y1, x0:x1] = 255
+
+
+def _label_row(cls, half, R, t):
+    box = np.concatenate([np.zeros((1, 3)), _corners(half)], 0)
+    p2, _ = fl._project(box, R, t)
+    lab = [float(cls)]
+    for k in range(9):
+        lab += [p2[k, 0] / W, p2[k, 1] / H]
+    lab += [(p2[:, 0].max() - p2[:, 0].min()) / W, (p2[:, 1].max() - p2[:, 1].min()) / H]
+    return lab
+
+
+def _pose(rs, sx=0.1, sy=0.1, z=(0.7, 1.2)):
+    R = fl._rodrigues(rs.standard_normal(3), rs.uniform(0, np.pi / 3))
+    t = np.array([rs.uniform(-sx, sx), rs.uniform(-sy, sy), rs.uniform(*z)])
+    return R, t
+
+
+def make(root, n_train=8, n_test=2, n_pasted=4, batch=4, max_epochs=1, seed=0, weights_seed=41, occlusion_labels='golden'):
+    """occlusion_labels: 'golden' = the rows stored in tests/golden/dropin_multi.json (see the module docstring), None = the
+    true projected boxes, or a dict {obj: {image name: 21 numbers}}."""
+    from PIL import Image
+    from oracle.darknet_ref import seeded_state, write_weights
+    from singleshotpose_amd.cfg import parse_cfg
+    if occlusion_labels == 'golden':
+        import json
+        occlusion_labels = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'dropin_multi.json')))['labels_occlusion']
+    rs = np.random.RandomState(seed)
+    multi = os.path.join(root, 'multi')
+    os.makedirs(os.path.join(multi, 'cfg'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages'), exist_ok=True)
+    objs = {}
+    for name in (SCENE,) + PASTED:
+        d = os.path.join(root, 'LINEMOD', name)
+        for sub in ('JPEGImages', 'mask', 'labels', 'labels_occlusion'):
+            os.makedirs(os.path.join(d, sub), exist_ok=True)
+        objs[name] = _object(rs, HALF[name])
+        _write_ply(os.path.join(d, name + '.ply'), *objs[name])
+    # ---- the pasted objects' own training images (image_multi.py:318-333 opens image, mask and label of a random one) ----
+    for name in PASTED:
+        d = os.path.join(root, 'LINEMOD', name)
+        lines = []
+        for i in range(n_pasted):
+            # anywhere in the frame: image_multi.py:337-349 re-draws a pasted object until it overlaps what is already there
+            # by less than a fifth of its area (the draws are pinned, so a run that ends once ends always)
+            R, t = _pose(rs, 0.3, 0.2, (0.9, 1.3))
+            img, mask = fl._texture(rs, H, W), np.zeros((H, W, 3), np.uint8)
+            _render(img, mask, *objs[name], R, t)
+            nm = '%06d' % i
+            Image.fromarray(img).save(os.path.join(d, 'JPEGImages', nm + '.png'))
+            Image.fromarray(mask).save(os.path.join(d, 'mask', nm[2:] + '.png'))
+            with open(os.path.join(d, 'labels', nm + '.txt'), 'w') as f:
+                f.write(' '.join('%.6f' % v for v in _label_row(CLASS_ID[name], HALF[name], R, t)) + '\n')
+            lines.append('LINEMOD/%s/JPEGImages/%s.png' % (name, nm))
+        with open(os.path.join(d, 'train.txt'), 'w') as f:       # image_multi.py:321 prefixes '../'
+            f.write('\n'.join(lines) + '\n')
+    # ---- the scenes: benchvise in front of a texture (train), plus the six evaluated objects around it (test) ----
+    d = os.path.join(root, 'LINEMOD', SCENE)
+    train, test = [], []
+    true_rows = {o: {} for o in VALID}
+    for i in range(n_train + n_test):
+        nm = '%06d' % i
+        img, mask = fl._texture(rs, H, W), np.zeros((H, W, 3), np.uint8)
+        R, t = _pose(rs, 0.05, 0.05)
+        if i >= n_train:
+            for k, o in enumerate(VALID):
+                Ro, to = _pose(rs, 0.02, 0.02)
+                to[:2] += np.array([(-0.3 + 0.12 * k), 0.18 * (1 if k % 2 else -1)])
+                _render(img, None, *objs[o], Ro, to)
+                true_rows[o][nm] = _label_row(CLASS_ID[o], HALF[o], Ro, to)
+        _render(img, mask, *objs[SCENE], R, t)
+        Image.fromarray(img).save(os.path.join(d, 'JPEGImages', nm + '.png'))
+        Image.fromarray(mask).save(os.path.join(d, 'mask', nm[2:] + '.png'))
+        with open(os.path.join(d, 'labels', nm + '.txt'), 'w') as f:
+            f.write(' '.join('%.6f' % v for v in _label_row(CLASS_ID[SCENE], HALF[SCENE], R, t)) + '\n')
+        (train if i < n_train else test).append('../LINEMOD/%s/JPEGImages/%s.png' % (SCENE, nm))
+    with open(os.path.join(multi, 'cfg', 'train_occlusion.txt'), 'w') as f:
+        f.write('\n'.join(train) + '\n')
+    for o in VALID:
+        do = os.path.join(root, 'LINEMOD', o)
+        with open(os.path.join(do, 'test_occlusion.txt'), 'w') as f:
+            f.write('\n'.join(test) + '\n')
+        for p in test:
+            nm = os.path.basename(p)[:-4]
+            row = (occlusion_labels or {}).get(o, {}).get(nm) or true_rows[o][nm]
+            with open(os.path.join(do, 'labels_occlusion', nm + '.txt'), 'w') as f:
+                f.write(' '.join('%.8f' % v for v in row) + '\n')
+        with open(os.path.join(multi, 'cfg', '%s_occlusion.data' % o), 'w') as f:
+            f.write('valid  = ../LINEMOD/%s/test_occlusion.txt\nmesh = ../LINEMOD/%s/%s.ply\nbackup = backup_multi\nname = %s\n'
+                    'diam = 0.1\ngpus = 0\nim_width = %d\nim_height = %d\nfx = %s\nfy = %s\nu0 = %s\nv0 = %s\n'
+                    % (o, o, o, o, W, H, FX, FY, U0, V0))
+    Image.fromarray(fl._texture(rs, 375, 500)).save(os.path.join(root, 'VOCdevkit', 'VOC2012', 'JPEGImages', 'bg0.png'))
+    with open(os.path.join(multi, 'cfg', 'occlusion.data'), 'w') as f:
+        f.write('train  = cfg/train_occlusion.txt\nbackup = backup_multi\ngpus = 0\nnum_workers = 0\nim_width = %d\nim_height = %d\n'
+                'fx = %s\nfy = %s\nu0 = %s\nv0 = %s\n' % (W, H, FX, FY, U0, V0))
+    out = []
+    for line in open(os.path.join(ROOT, 'cfg', 'yolo-pose-multi.cfg')).read().split('\n'):
+        key = line.split('=')[0].strip()
+        if key == 'batch':
+            line = 'batch=%d' % batch
+        elif key == 'max_epochs':
+            line = 'max_epochs = %d' % max_epochs
+        out.append(line)
+    cfgfile = os.path.join(multi, 'cfg', 'yolo-pose-multi.cfg')
+    with open(cfgfile, 'w') as f:
+        f.write('\n'.join(out))
+    blocks = parse_cfg(cfgfile)
+    state = seeded_state(blocks, weights_seed)
+    # head (5 anchors x (18 coordinates, confidence, 13 classes)): as in fixture_linemod.make - tiny image-dependent weights
+    # on the coordinate channels over a bias that draws a canonical box (PnP is well posed on it), full-size weights on
+    # the confidence and class channels so that which cell / anchor / class wins is decided by margins far above 1e-4
+    head = [e for e in state if e is not None][-1]
+    import torch
+    bias = np.zeros(160, dtype=np.float32)
+    Rc = fl._rodrigues(np.array([1.0, 1.0, 0.0]), 0.5)
+    pc, _ = fl._project(np.concatenate([np.zeros((1, 3)), _corners(HALF['cat'])], 0), Rc, np.array([0.0, 0.0, 0.9]))
+    for a in range(5):
+        o = a * 32
+        head['weight'][o:o + 18] *= 0.0002
+        head['weight'][o + 18:o + 32] *= 0.1
+        for k in range(1, 9):
+            bias[o + 2 * k] = 0.5 + (pc[k, 0] - pc[0, 0]) / W * 13
+            bias[o + 2 * k + 1] = 0.5 + (pc[k, 1] - pc[0, 1]) / H * 13
+    head['bias'] = torch.from_numpy(bias)
+    write_weights(os.path.join(multi, 'init.weights'), blocks, state)
+    return dict(root=root, cwd=multi, n_train=n_train, n_test=n_test, batch=batch, test_images=[os.path.basename(p)[:-4] for p in test])
+
+
+# ---- parsing what the drivers print (region_loss_multi.py:178, valid_multi.py:66,158) ----
+def parse_train_output(text):
+    import re
+    rows = []
+    for m in re.finditer(r'^(\d+): nGT (\d+), recall (\d+), proposals (\d+), loss: x ([-\d.eE+]+), y ([-\d.eE+]+), '
+                         r'conf ([-\d.eE+]+), cls ([-\d.eE+]+), total ([-\d.eE+]+)$', text, re.M):
+        g = m.groups()
+        rows.append(dict(seen=int(g[0]), nGT=int(g[1]), recall=int(g[2]), proposals=int(g[3]), loss_x=float(g[4]),
+                         loss_y=float(g[5]), loss_conf=float(g[6]), loss_cls=float(g[7]), total=float(g[8])))
+    lr = re.findall(r'epoch (\d+), processed (\d+) samples, lr ([-\d.eE+]+)', text)
+    return dict(steps=rows, epochs=[dict(epoch=int(a), processed=int(b), lr=float(c)) for a, b, c in lr])
+
+
+def parse_valid_output(text):
+    """{object: [accuracy at 5, 10, ..., 50 px]} in the order valid_multi.py tests the objects."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r'Testing (\w+)\.\.\.', line)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+        m = re.search(r'Acc using (\d+) px 2D Projection = ([-\d.]+)%', line)
+        if m and cur is not None:
+            out[cur].append(float(m.group(2)))
+    return out

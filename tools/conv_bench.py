@@ -48,7 +48,7 @@ def main():
         touched = set()
         for cfg in args.sweep.split(';'):
             for name in touched:
-                _lib.call('ssp_set_option', name.encode(), 1 if name == 'igemm_xcd' else 0)
+                _lib.call('ssp_set_option', name.encode(), 1 if name in ('igemm_xcd', 'acc_chunk') else 0)
             touched = set()
             for kv in filter(None, (cfg if cfg != '-' else '').split(',')):
                 k, v = kv.split('=')
