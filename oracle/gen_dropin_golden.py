@@ -68,5 +68,109 @@ def main():
     print(json.dumps(rt, indent=1))
 
 
+def _pixel_dist(pred_px, gt_corrected_px, vertices, corners3D, K):
+    """valid_multi.py:122-140 for one (prediction, ground truth) pair: mean reprojection distance of the mesh vertices
+    between the two PnP poses (oracle/pnp_ref.py stands in for cv2, as in the harness)."""
+    import numpy as np
+    from oracle.pnp_ref import solve_pnp_ref
+    obj = np.concatenate((np.zeros((3, 1)), corners3D[:3, :]), axis=1).T.astype(np.float32).astype(np.float64)
+    out = []
+    for pts in (gt_corrected_px, pred_px):
+        R, t = solve_pnp_ref(obj, np.asarray(pts, dtype=np.float32).astype(np.float64), K.astype(np.float32).astype(np.float64))
+        Rt = np.concatenate((R, t.reshape(3, 1)), axis=1)
+        cam = K.dot(Rt.dot(vertices))
+        out.append(cam[:2] / cam[2])
+    return float(np.mean(np.linalg.norm(out[0] - out[1], axis=0)))
+
+
+def main_multi():
+    """tests/golden/dropin_multi.json: the reference's UNMODIFIED train_multi.py and valid_multi.py on the CPU reference over
+    the OCCLUSION-shaped fixture (tests/fixture_occlusion.py), plus the labels_occlusion rows that fixture needs."""
+    import numpy as np
+    import fixture_occlusion as fo
+    from oracle.stage_reference import stage
+    stage()
+    harness = os.path.join(ROOT, 'oracle', 'run_reference_cpu.py')
+    mdir = os.path.join(REF, 'multi_obj_pose_estimation')
+    env = dict(os.environ)
+    env.pop('PYTHONPATH', None)
+
+    def run(cwd, *cmd):
+        return subprocess.run([sys.executable, harness] + list(cmd), cwd=cwd, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, check=True).stdout
+    tmp = tempfile.mkdtemp(prefix='ssp_fixture_multi_')
+    try:
+        # phase 1: the true projected boxes as labels; what does the reference network predict per (object, test image)?
+        info = fo.make(tmp, occlusion_labels=None)
+        run(info['cwd'], os.path.join(ROOT, 'oracle', 'multi_predictions.py'), 'cfg/yolo-pose-multi.cfg', 'init.weights',
+            os.path.join(tmp, 'pred.json'))
+        pred = json.load(open(os.path.join(tmp, 'pred.json')))
+        # labels_occlusion rows: fix_corner_order(label) = prediction + a per-sample offset, so that the reference's own
+        # pixel error of that sample is a known 3 ... 57 px, at least 1.2 px from every threshold valid_multi.py:149 counts with
+        K = np.array([[fo.FX, 0, fo.U0], [0, fo.FY, fo.V0], [0, 0, 1.0]])
+        labels, dists = {}, {}
+        mags = [3, 8, 13, 18, 23, 28, 33, 38, 43, 57, 6, 16, 27, 36, 47, 52]
+        n = 0
+        for oi, obj in enumerate(fo.VALID):
+            import fixture_linemod as fl
+            verts = []
+            for line in open(os.path.join(tmp, 'LINEMOD', obj, obj + '.ply')).read().split('end_header\n')[1].splitlines():
+                v = line.split()
+                if len(v) == 9:
+                    verts.append([float(v[0]), float(v[1]), float(v[2])])
+            vertices = np.c_[np.array(verts), np.ones((len(verts), 1))].T
+            mn, mx = vertices[:3].min(axis=1), vertices[:3].max(axis=1)
+            corners3D = np.array([[(mx if a else mn)[0], (mx if b else mn)[1], (mx if c else mn)[2]]
+                                  for a in (0, 1) for b in (0, 1) for c in (0, 1)]).T
+            labels[obj], dists[obj] = {}, {}
+            for name in info['test_images']:
+                p = np.array(pred[obj][name]['points_px'])
+                ang = 0.7 + 1.3 * n
+                mag = float(mags[n % len(mags)])
+                for _ in range(40):
+                    gt_corr = p + mag * np.array([np.cos(ang), np.sin(ang)])
+                    d = _pixel_dist(p, gt_corr, vertices, corners3D, K)
+                    if min(abs(d - th) for th in range(5, 55, 5)) > 1.2:
+                        break
+                    mag += 0.7
+                gt = np.zeros((9, 2))
+                for k in range(9):
+                    gt[fo.PERM[k]] = gt_corr[k]          # fix_corner_order: corrected[k] = gt[PERM[k]]
+                row = [float(pred[obj][name]['cls'])]
+                for k in range(9):
+                    row += [gt[k, 0] / fo.W, gt[k, 1] / fo.H]
+                row += [(gt[:, 0].max() - gt[:, 0].min()) / fo.W, (gt[:, 1].max() - gt[:, 1].min()) / fo.H]
+                labels[obj][name] = [float('%.8f' % v) for v in row]
+                dists[obj][name] = round(d, 3)
+                n += 1
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        # phase 2: the fixture as the tests build it; the two unmodified drivers on the CPU reference
+        info = fo.make(tmp, occlusion_labels=labels)
+        v = run(info['cwd'], os.path.join(mdir, 'valid_multi.py'), '--modelcfg', 'cfg/yolo-pose-multi.cfg', '--initweightfile', 'init.weights')
+        targs = (os.path.join(mdir, 'train_multi.py'), '--datacfg', 'cfg/occlusion.data', '--modelcfg',
+                 'cfg/yolo-pose-multi.cfg', '--initweightfile', 'init.weights')
+        t = run(info['cwd'], *targs)
+        # the same run under another summation order (one OpenMP thread): how far the reference is from ITSELF on the batch
+        # after the first optimizer step - sizes the envelope of the second step in tests/test_gpu_dropin.py
+        env['OMP_NUM_THREADS'] = env['MKL_NUM_THREADS'] = '1'
+        t1 = run(info['cwd'], *targs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    tr = fo.parse_train_output(t)
+    tr['steps_one_thread'] = fo.parse_train_output(t1)['steps']
+    rec = dict(labels_occlusion=labels, expected_pixel_dist=dists, valid=fo.parse_valid_output(v), train=tr,
+               _meta=dict(generator='oracle/gen_dropin_golden.py main_multi', fixture='tests/fixture_occlusion.py make()',
+                          scripts='/root/reference/multi_obj_pose_estimation/{train_multi,valid_multi}.py (unmodified) on the CPU '
+                                  'reference (oracle/run_reference_cpu.py), randomness pinned (seed 0)',
+                          pnp='oracle/pnp_ref.py (OpenCV ITERATIVE restated; cv2 itself is not installable here)'))
+    json.dump(rec, open(os.path.join(ROOT, 'tests', 'golden', 'dropin_multi.json'), 'w'), indent=1, sort_keys=True)
+    print(json.dumps({k: rec[k] for k in ('expected_pixel_dist', 'valid', 'train')}, indent=1))
+    print(t[-1500:])
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'multi':
+        main_multi()
+    else:
+        main()

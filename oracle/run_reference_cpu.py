@@ -3,6 +3,7 @@
 
 TEST INFRASTRUCTURE, build container only (needs /root/reference):
     python oracle/run_reference_cpu.py [--seed N] /root/reference/valid.py --datacfg ... (cwd = the fixture directory)
+    python oracle/run_reference_cpu.py /root/reference/multi_obj_pose_estimation/train_multi.py ...   (cwd = fixture/multi)
 
 The script and every module it imports (darknet.py, utils.py, dataset.py, image.py, MeshPly.py, cfg.py) are the
 reference's own files, imported from where they lie.  What this harness supplies around them, because the reference
@@ -23,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
 
 
-def install():
+def install(multi=False):
     import numpy as np
     import torch
     sys.path.insert(0, ROOT)
@@ -52,18 +53,28 @@ def install():
     sys.path.insert(0, os.path.join(ROOT, 'dropin'))
     sys.path.insert(0, REF)
     sys.modules['region_loss'] = load_patched(os.path.join(REF, 'region_loss.py'), 'region_loss')
+    if multi:
+        # multi_obj_pose_estimation/: darknet_multi, utils_multi, dataset_multi, image_multi are the reference's own files;
+        # region_loss_multi.py gets the same three mechanical patches as region_loss.py
+        mdir = os.path.join(REF, 'multi_obj_pose_estimation')
+        sys.path.insert(0, mdir)
+        sys.modules['region_loss_multi'] = load_patched(os.path.join(mdir, 'region_loss_multi.py'), 'region_loss_multi')
 
 
 def main(argv):
     seed = 0
     if argv and argv[0] == '--seed':
         seed, argv = int(argv[1]), argv[2:]
-    install()
+    install(multi='multi' in os.path.basename(argv[0]))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from run_pinned import pin
     pin(seed)
     sys.argv = argv
-    runpy.run_path(argv[0], run_name='__main__')
+    # executed as `python script.py` would: __name__ == '__main__' and __package__ None (valid_multi.py:161 tests both;
+    # runpy.run_path would set __package__ to '')
+    path = os.path.abspath(argv[0])
+    glb = {'__name__': '__main__', '__package__': None, '__file__': path, '__builtins__': __builtins__}
+    exec(compile(open(path).read(), path, 'exec'), glb)
 
 
 if __name__ == '__main__':

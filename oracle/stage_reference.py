@@ -23,7 +23,11 @@ DST = os.path.join(ROOT, 'oracle', '_ref')
 # driver scripts + the helper modules they import that are OUT of this repo's scope (PIL data pipeline, mesh reader);
 # darknet.py / region_loss.py / utils.py / cfg.py are deliberately NOT in this archive: for the drivers those names
 # resolve to dropin/
-CALLERS = ('valid.py', 'train.py', 'dataset.py', 'image.py', 'MeshPly.py')
+CALLERS = ('valid.py', 'train.py', 'dataset.py', 'image.py', 'MeshPly.py',
+           # BASELINE config 5: the multi-object drivers and THEIR data pipeline (darknet_multi / region_loss_multi / utils_multi
+           # resolve to dropin/multi_obj_pose_estimation/)
+           'multi_obj_pose_estimation/train_multi.py', 'multi_obj_pose_estimation/valid_multi.py',
+           'multi_obj_pose_estimation/dataset_multi.py', 'multi_obj_pose_estimation/image_multi.py')
 # the hot path's own modules, for the CPU baseline only (never on sys.path of a test or of the product)
 MODULES = ('darknet.py', 'region_loss.py', 'utils.py', 'cfg.py')
 

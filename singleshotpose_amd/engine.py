@@ -450,7 +450,9 @@ class Plan(object):
                             continue
                         if t_ is not None and cs.fwd_fams[0][1] is not None and t_ >= cs.fwd_fams[0][1]:
                             continue      # slower than the direct code: never an option
-                        d = float((run(dict(direct, **{cs.ind: c_})) - ref).abs().max()) / den
+                        assign = dict(direct)
+                        assign[cs.ind] = c_
+                        d = float((run(assign) - ref).abs().max()) / den
                         rows.append((f_, c_, t_, d))
                     rows.sort(key=lambda r: (r[2] if r[2] is not None else 0.0))
                     table[cs.ind] = rows

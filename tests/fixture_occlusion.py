@@ -95,7 +95,7 @@ def _pose(rs, sx=0.1, sy=0.1, z=(0.7, 1.2)):
     return R, t
 
 
-def make(root, n_train=8, n_test=2, n_pasted=4, batch=4, max_epochs=1, seed=0, weights_seed=41, occlusion_labels='golden'):
+def make(root, n_train=8, n_test=4, n_pasted=4, batch=4, max_epochs=1, seed=0, weights_seed=41, occlusion_labels='golden'):
     """occlusion_labels: 'golden' = the rows stored in tests/golden/dropin_multi.json (see the module docstring), None = the
     true projected boxes, or a dict {obj: {image name: 21 numbers}}."""
     from PIL import Image
@@ -187,7 +187,8 @@ def make(root, n_train=8, n_test=2, n_pasted=4, batch=4, max_epochs=1, seed=0, w
     state = seeded_state(blocks, weights_seed)
     # head (5 anchors x (18 coordinates, confidence, 13 classes)): as in fixture_linemod.make - tiny image-dependent weights
     # on the coordinate channels over a bias that draws a canonical box (PnP is well posed on it), full-size weights on
-    # the confidence and class channels so that which cell / anchor / class wins is decided by margins far above 1e-4
+    # the class channels and moderate ones on the confidence channel, so that which cell / anchor / class wins is decided by
+    # margins far above 1e-4
     head = [e for e in state if e is not None][-1]
     import torch
     bias = np.zeros(160, dtype=np.float32)
@@ -196,7 +197,8 @@ def make(root, n_train=8, n_test=2, n_pasted=4, batch=4, max_epochs=1, seed=0, w
     for a in range(5):
         o = a * 32
         head['weight'][o:o + 18] *= 0.0002
-        head['weight'][o + 18:o + 32] *= 0.1
+        head['weight'][o + 18] *= 0.02            # confidence logits of +-2, not +-9: sigmoid keeps the candidates apart
+        head['weight'][o + 19:o + 32] *= 0.1
         for k in range(1, 9):
             bias[o + 2 * k] = 0.5 + (pc[k, 0] - pc[0, 0]) / W * 13
             bias[o + 2 * k + 1] = 0.5 + (pc[k, 1] - pc[0, 1]) / H * 13
