@@ -437,6 +437,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        # `python bench.py --gpus N` without a launcher must never measure ONE rank and print it as N: start the N ranks here
+        # (one process per GPU through torch.distributed.run, as the driver does) - or stop with a non-zero status
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); nothing measured (launch one rank per GPU: "
+                             "tools/launch_dp.sh %d, or python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...)"
+                             % (args.gpus, have, args.gpus, args.gpus, args.gpus))
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
@@ -465,6 +483,9 @@ def main():
     # torch.optim.SGD's update rule (train.py:388) as one fused launch over the flat parameter/gradient/momentum buffers
     opt = SGD(model.parameters(), lr=1e-3 / global_batch, momentum=0.9, dampening=0, weight_decay=0.0005 * global_batch)
     reducer = GradReducer(model, world, force=dist_on and world == 1)
+    if world > 1:
+        from singleshotpose_amd.dist import sync_plans
+        sync_plans(model)        # every rank runs rank 0's plan set (same shape on every rank here: the broadcasts pair up)
     x, tgt = synthetic_batch(B, H, W, 1000 + rank, device)
 
     def step():

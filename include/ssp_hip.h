@@ -165,7 +165,11 @@ int ssp_colsum(const float* g, int ldg, int64_t M, int C, float* out, void* stre
  *   fwd_apply : out[pooled pixel][0..32) = maxpool2x2(leaky(scale * conv + shift))
  *   bwd_reduce: partial[groups][32][2] = (sum dy, sum dy * xhat) from g = dL/d out (pool arg-max = first maximum in
  *               window scan order, as ATen); feed ssp_bn_bwd_finalize
- *   bwd_wgrad : dw[32][9][4] += filter gradient (dx formed in registers from g, the recomputed conv and c1 / c2)  */
+ *   bwd_wgrad : dw[32][9][4] = filter gradient (dx formed in registers from g, the recomputed conv and c1 / c2; the padding
+ *               channel written as zero).  Two launches: every workgroup leaves its partial gradient in `workspace`
+ *               (ssp_first_wgrad_workspace_floats(B,H,W) floats), a second kernel sums the workgroups in float64 - the
+ *               gradient is a sum of terms that cancel ~1e3 : 1, and deterministic this way (ABI 4; ABI 3 accumulated
+ *               with fp32 atomics into a zeroed dw)  */
 int ssp_first_tile_pixels(void);
 int ssp_first_groups(int B, int H, int W);
 int ssp_first_fwd_stats(const float* x, const float* wt, float* stats, int B, int H, int W, void* stream);
@@ -179,7 +183,8 @@ int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ld
                          void* stream);
 int ssp_first_bwd_wgrad(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* c1, const float* c2, float slope, float* dw,
-                        int B, int H, int W, void* stream);
+                        float* workspace, int64_t workspace_floats, int B, int H, int W, void* stream);
+int64_t ssp_first_wgrad_workspace_floats(int B, int H, int W);
 
 /* ---- optimizer ------------------------------------------------------------------ */
 /* One torch.optim.SGD step (train.py:388,106) over a contiguous fp32 range of n values, in place:

@@ -56,7 +56,8 @@ _SIGS = {
     "ssp_first_fwd_apply": [P, P, P, P, F, P, I, I, I, I, P],
     "ssp_first_conv_raw": [P, P, P, I, I, I, I, P],
     "ssp_first_bwd_reduce": [P, P, P, I, P, P, P, P, F, P, I, I, I, P],
-    "ssp_first_bwd_wgrad": [P, P, P, I, P, P, P, P, P, P, F, P, I, I, I, P],
+    "ssp_first_bwd_wgrad": [P, P, P, I, P, P, P, P, P, P, F, P, P, L, I, I, I, P],
+    "ssp_first_wgrad_workspace_floats": [I, I, I],
     "ssp_colsum": [P, I, L, I, P, P],
     "ssp_pose_errors": [P, I, P, P, P, I, I, P, P],
     "ssp_pts_diameter": [P, I, P, P, P],
@@ -84,7 +85,7 @@ _SIGS = {
 }
 
 _RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats_t',
-          'ssp_conv_stats_floats', 'ssp_conv_wino_tiles')
+          'ssp_conv_stats_floats', 'ssp_conv_wino_tiles', 'ssp_first_wgrad_workspace_floats')
 
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
               "first_block_bwd", "wino_fwd", "wino_dgrad", "wino_wgrad")

@@ -42,7 +42,8 @@ struct FirstArgs {
   float* out; int ldo;          // pooled activation [B*Ho*Wo][ldo]
   const float* g; int ldg;      // gradient wrt the pooled activation
   float* stats;                 // fwd_stats: [nwg][32][2] (mean, M2); bwd_reduce: [nwg][32][2] (sum dy, sum dy*xhat)
-  float* dw;                    // [32][9][4] filter gradient, accumulated with atomics
+  float* dw;                    // [32][9][4] filter gradient (written by first_wgrad_finalize_kernel)
+  float* wpart;                 // bwd_wgrad: [nwg][32 * 27] per-workgroup partial filter gradients
 };
 
 struct FirstBlock {
@@ -148,9 +149,12 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
   // running results
   float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;          // MODE 0
   double s1 = 0.0, s2 = 0.0;                             // MODE 2
-  f32x16 accw;                                           // MODE 3: dW[cout = row][j' = col = lane&31]
+  // MODE 3: dW[cout = row][j' = col = lane&31].  A wave's 64 blocks are 1024 MFMA steps into one accumulator - summed in
+  // groups of 8 blocks (accw -> acct), as conv_igemm_dma.hip does: the terms cancel ~1e3 : 1 in this gradient (sum dx = 0
+  // exactly over an all-positive image), so the length of the fp32 chain is what its error is made of
+  f32x16 accw, acct;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { accw[r] = 0.f; acct[r] = 0.f; }
   // MODE 3 B operand (input patch value for column j' = tap*3 + ci of the filter gradient): fixed lane offset
   const int jt = li / 3, jc = li - jt * 3;               // lane's (tap, input channel); li >= 27: no such column
   // bytes from pixel (y-1, x-1) of the step's first pixel: never negative (a "negative" vector offset is out of range
@@ -265,7 +269,15 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) xa[t] = xn[t];
     }
+    if constexpr (MODE == 3) {
+      if ((ib & 7) == 7) {
+        acct += accw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+      }
+    }
   }
+  if constexpr (MODE == 3) accw += acct;
 
   // ---- workgroup results ----
   __shared__ __attribute__((aligned(16))) float red[4][32][32];
@@ -301,13 +313,35 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = accw[r];
     __syncthreads();
+    // this workgroup's partial gradient, a row of its own: the workgroups are summed in float64 by
+    // first_wgrad_finalize_kernel (1352 fp32 atomics per element at 416 x 416, batch 64, were one more long fp32 chain -
+    // and made the result depend on the order the workgroups retired in)
     for (int e = tid; e < 32 * 27; e += 256) {
       const int co = e / 27, j = e - co * 27;
-      const float v = red[0][co][j] + red[1][co][j] + red[2][co][j] + red[3][co][j];
-      atomicAdd(p.dw + co * 36 + (j / 3) * 4 + j % 3, v);
+      p.wpart[(int64_t)blockIdx.x * (32 * 27) + e] = red[0][co][j] + red[1][co][j] + red[2][co][j] + red[3][co][j];
     }
   }
 #endif
+}
+
+// dw[co][tap][ci] = sum over the workgroups' partials, in float64 (thread = (element of a group of 32, one of 8 slices of the
+// workgroup range), LDS reduce over the slices); the padding channel of the [32][9][4] layout is written as zero
+__global__ void __launch_bounds__(256) first_wgrad_finalize_kernel(const float* __restrict__ wpart, int nwg, float* __restrict__ dw) {
+  const int tid = threadIdx.x, el = tid & 31, sl = tid >> 5;
+  const int e = blockIdx.x * 32 + el;                    // 27 blocks x 32 = 864 elements
+  double a = 0.0;
+  for (int w = sl; w < nwg; w += 8) a += (double)wpart[(int64_t)w * (32 * 27) + e];
+  __shared__ double red[8][32];
+  red[sl][el] = a;
+  __syncthreads();
+  if (sl == 0) {
+    double t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][el];
+    const int co = e / 27, j = e - co * 27;
+    dw[co * 36 + (j / 3) * 4 + j % 3] = (float)t;
+    if (e < 32 * 9) dw[e * 4 + 3] = 0.f;
+  }
 }
 
 static int first_check(const float* x, const float* wt, int B, int H, int W, const char* who) {
@@ -385,17 +419,28 @@ int ssp_first_bwd_reduce_launch(const float* x, const float* wt, const float* g,
   return SSP_OK;
 }
 
+int64_t ssp_first_wgrad_workspace_floats_impl(int B, int H, int W) {
+  return (int64_t)ssp_cdiv((int64_t)B * (H / 2) * (W / 16), 256) * (32 * 27);
+}
+
 int ssp_first_bwd_wgrad_launch(const float* x, const float* wt, const float* g, int ldg, const float* scale,
                                const float* shift, const float* mean, const float* invstd, const float* c1,
-                               const float* c2, float slope, float* dw, int B, int H, int W, hipStream_t stream) {
+                               const float* c2, float slope, float* dw, float* workspace, int64_t workspace_floats, int B,
+                               int H, int W, hipStream_t stream) {
   if (int rc = first_check(x, wt, B, H, W, "first_bwd_wgrad")) return rc;
   SSP_CHECK_ARG(g != nullptr && ldg >= FIRST_COUT && dw != nullptr, "first_bwd_wgrad: null gradient operand");
-  // fewer, longer workgroups: each ends with 864 atomics onto the same filter gradient
+  SSP_CHECK_ARG(workspace != nullptr && workspace_floats >= ssp_first_wgrad_workspace_floats_impl(B, H, W),
+                "first_bwd_wgrad: needs a workspace of %lld floats (ssp_first_wgrad_workspace_floats)",
+                (long long)ssp_first_wgrad_workspace_floats_impl(B, H, W));
+  // fewer, longer workgroups (64 blocks per wave): each ends with one 864-float row of the partial buffer
   FirstArgs a = first_args(x, wt, B, H, W, 64);
   a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2; a.slope = slope;
-  a.g = g; a.ldg = ldg; a.dw = dw;
+  a.g = g; a.ldg = ldg; a.dw = dw; a.wpart = workspace;
   SspProfScope prof(SSP_PROF_FIRST_BWD, stream, 2.0 * (double)B * H * W * FIRST_COUT * 27.0);
-  hipLaunchKernelGGL(first_block_kernel<3>, dim3(ssp_cdiv(a.nblocks, 256)), dim3(256), 0, stream, a);
+  const int nwg = ssp_cdiv(a.nblocks, 256);
+  hipLaunchKernelGGL(first_block_kernel<3>, dim3(nwg), dim3(256), 0, stream, a);
   SSP_CHECK_LAUNCH("first_bwd_wgrad");
+  hipLaunchKernelGGL(first_wgrad_finalize_kernel, dim3(27), dim3(256), 0, stream, workspace, nwg, dw);
+  SSP_CHECK_LAUNCH("first_wgrad_finalize");
   return SSP_OK;
 }

@@ -51,7 +51,9 @@ int ssp_first_bwd_reduce_launch(const float* x, const float* wt, const float* g,
                                 int B, int H, int W, hipStream_t stream);
 int ssp_first_bwd_wgrad_launch(const float* x, const float* wt, const float* g, int ldg, const float* scale,
                                const float* shift, const float* mean, const float* invstd, const float* c1,
-                               const float* c2, float slope, float* dw, int B, int H, int W, hipStream_t stream);
+                               const float* c2, float slope, float* dw, float* workspace, int64_t workspace_floats, int B,
+                               int H, int W, hipStream_t stream);
+int64_t ssp_first_wgrad_workspace_floats_impl(int B, int H, int W);
 int ssp_colsum_launch(const float* g, int ldg, int64_t M, int C, float* out, hipStream_t stream);
 int ssp_sgd_step_launch(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float dampening,
                         float weight_decay, int nesterov, int first_step, hipStream_t stream);
@@ -164,7 +166,7 @@ SspProfScope::~SspProfScope() {
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err; }
-int ssp_abi_version(void) { return 3; }
+int ssp_abi_version(void) { return 4; }
 int ssp_set_option(const char* name, int value) {
   for (int i = 0; i < SSP_OPT_COUNT; ++i)
     if (name != nullptr && strcmp(name, g_option_names[i]) == 0) {
@@ -266,10 +268,11 @@ int ssp_first_bwd_reduce(const float* x, const float* wt, const float* g, int ld
 }
 int ssp_first_bwd_wgrad(const float* x, const float* wt, const float* g, int ldg, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* c1, const float* c2, float slope, float* dw,
-                        int B, int H, int W, void* stream) {
-  return ssp_first_bwd_wgrad_launch(x, wt, g, ldg, scale, shift, mean, invstd, c1, c2, slope, dw, B, H, W,
-                                    (hipStream_t)stream);
+                        float* workspace, int64_t workspace_floats, int B, int H, int W, void* stream) {
+  return ssp_first_bwd_wgrad_launch(x, wt, g, ldg, scale, shift, mean, invstd, c1, c2, slope, dw, workspace,
+                                    workspace_floats, B, H, W, (hipStream_t)stream);
 }
+int64_t ssp_first_wgrad_workspace_floats(int B, int H, int W) { return ssp_first_wgrad_workspace_floats_impl(B, H, W); }
 
 int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                    int ldx, int R, void* stream) {

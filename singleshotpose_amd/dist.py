@@ -19,7 +19,12 @@ import torch.distributed as dist
 
 
 def init_distributed(backend=None):
-    """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run)."""
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run).
+
+    Call order: this function first - it binds the process to ITS GPU (LOCAL_RANK) before
+    anything creates a HIP context or a stream, then creates the engine's second compute stream, then the process group.
+    A process that reaches it with another current device than its LOCAL_RANK's (somebody already called
+    torch.cuda.set_device) keeps that choice; one that never chose gets cuda:LOCAL_RANK, not cuda:0 for every rank."""
     if dist.is_initialized():
         return
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -27,12 +32,44 @@ def init_distributed(backend=None):
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # "nccl" is RCCL on ROCm
     if backend == 'nccl' and torch.cuda.is_available():
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if local < torch.cuda.device_count() and (not torch.cuda.is_initialized() or torch.cuda.current_device() == 0):
+            torch.cuda.set_device(local)
+        elif torch.cuda.current_device() != local:
+            import warnings
+            warnings.warn("singleshotpose_amd.dist: LOCAL_RANK is %d but the current device is cuda:%d - the side stream and the "
+                          "process group are created on cuda:%d" % (local, torch.cuda.current_device(), torch.cuda.current_device()))
         # the engine's second compute stream first: HIP hands its streams to a few hardware queues in creation order, and
         # behind RCCL's own streams it would share the main stream's queue (engine._side_stream)
         from .engine import _side_stream
         _side_stream(torch.device('cuda', torch.cuda.current_device()))
     dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')),
                             world_size=int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def sync_plans(model, group=None):
+    """Every rank runs the SAME kernel plan set: rank 0's.
+
+    The autotuner times candidates per process, and a near-tie can fall either way on two GPUs: ranks would then run
+    different tile / split / Winograd choices - different fp32 rounding in the forward pass and in the BatchNorm statistics
+    (gradients agree after the all-reduce either way), and different step times, which in weak scaling show up as
+    all-reduce wait on the faster ranks.  With this hook installed every plan, right after its own tuning (forward codes
+    after the head-error budget; data- and filter-gradient codes after theirs), takes part in ONE broadcast of rank 0's
+    codes and adopts them.  The payload carries the plan's shape: a rank whose plan is of another shape keeps its own codes.
+    Requirement: all ranks build their plans in the same order (same sequence of input shapes) - bench.py and a training
+    loop whose multi-scale schedule is seeded identically on every rank; a loop whose ranks draw shapes independently
+    must not install it (the broadcasts would pair up wrongly)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        model._plan_sync = None
+        return None
+
+    def fn(values):
+        dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        return [int(v) for v in t.tolist()]
+    model._plan_sync = fn
+    return fn
 
 
 class GradReducer(object):

@@ -489,6 +489,40 @@ class Plan(object):
         self._fit_workspace()
         self.head_budget = rec
 
+    def _sync_codes(self, stage):
+        """Multi-GPU: adopt rank 0's plan codes (singleshotpose_amd.dist.sync_plans installs the hook on the model).
+        stage 0: forward codes (called once, on the plan's first training forward, after the head-error budget);
+        stage 1: data-gradient codes and the filter gradients' direct / Winograd choice (after their tuning)."""
+        fn = getattr(self.net, '_plan_sync', None)
+        if fn is None:
+            return
+        order = sorted(self.convs)
+        if stage == 0:
+            mine = [self.convs[i].plan_fwd for i in order]
+        else:
+            mine = [self.convs[i].plan_dgrad for i in order] + [getattr(self.convs[i], 'wgrad_wino', 0) for i in order]
+        head = [self.B, self.H, self.W, stage, len(order)]
+        got = fn(head + mine)
+        if got[:5] != head or len(got) != len(head) + len(mine):
+            return                       # rank 0's plan is of another shape: keep this rank's own choices
+        vals = got[5:]
+        for k, i in enumerate(order):
+            cs = self.convs[i]
+            if stage == 0:
+                if vals[k] != cs.plan_fwd:
+                    cs.plan_fwd = vals[k]
+                    self._size_layer(cs)
+            else:
+                cs.plan_dgrad = vals[k]
+                w = vals[len(order) + k]
+                if w != getattr(cs, 'wgrad_wino', 0):
+                    cs.wgrad_wino = w
+                    if w:
+                        cs.wino_ws_floats = _lib.query('ssp_conv_wgrad_wino_workspace_floats_t', self.B, cs.H, cs.W, cs.cinp, cs.cout, w)
+                    cs.wino_ws = None
+        if stage == 0:
+            self._fit_workspace()
+
     def _fit_workspace(self):
         need = max([1] + [cs.ws_fwd for cs in self.convs.values()] + [getattr(cs, 'ws_dgrad', 0) for cs in self.convs.values()])
         if need > self.ws_floats:
@@ -520,7 +554,7 @@ class Plan(object):
         ts += [g.t for g in self.grads.values()]
         for cs in self.convs.values():
             ts += [cs._raw, cs.vec, getattr(cs, 'stats', None), getattr(cs, 'first_partial', None), getattr(cs, 'wbuf', None),
-                   getattr(cs, 'gbuf', None), getattr(cs, 'wino_ws', None)]
+                   getattr(cs, 'gbuf', None), getattr(cs, 'wino_ws', None), getattr(cs, 'first_wpart', None)]
             ts += list((getattr(cs, 'wino_u', None) or {}).values()) + list((getattr(cs, 'wino_ud', None) or {}).values())
             bnp = getattr(cs, 'bnp', None)
             if bnp is not None:
@@ -598,6 +632,8 @@ class Plan(object):
                 code = _TUNE_CACHE.get(key, 0)
                 cs.plan_dgrad = code if _TUNE_VERIFIED.get(key) == code and (not wino_tile(code) or wino_on) else 0
                 cs.wgrad_wino = 0
+        if tune:
+            self._sync_codes(1)              # multi-GPU: ... and rank 0's data- / filter-gradient choices
         need = 1
         for cs in self.convs.values():
             cs.ws_dgrad = 0 if cs.first else _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.coutp,
@@ -1017,6 +1053,7 @@ class Plan(object):
         self._sg_fwd_live = False
         if training and need_grad and not self._head_budget_done:
             self._apply_head_budget()        # once per plan, on its first training batch (network-level rounding budget)
+            self._sync_codes(0)              # multi-GPU: every rank runs rank 0's forward codes
         if self._step_graph_mode(training, need_grad, inline_repack):
             key = self._sg_key()
             if self._sg_fwd is not None and self._sg_fwd[0] == key:
@@ -1402,7 +1439,7 @@ class Plan(object):
         written.add(self.last)
         flat.zero_()
         for cs in self.convs.values():          # gradient staging of the parameters that are not channels-last
-            if not cs.packed:
+            if not cs.packed and not cs.first_live:      # (the fused first block's filter gradient is WRITTEN, not accumulated)
                 self._gbuf(cs).zero_()
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
@@ -1468,9 +1505,12 @@ class Plan(object):
                     if not tail_sched:
                         side.wait_stream(main)
                     gw = gview(cs.conv.weight, False)
+                    if getattr(cs, 'first_wpart', None) is None:      # per-workgroup partial gradients, summed in float64
+                        cs.first_wpart = torch.empty(_lib.query('ssp_first_wgrad_workspace_floats', B, cs.H, cs.W),
+                                                     dtype=torch.float32, device=self.device)
                     call('ssp_first_bwd_wgrad', cs.inp.ptr, wptr, g.ptr, g.ld, v[2].data_ptr(), v[3].data_ptr(),
                          v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(), v[5].data_ptr(), cs.slope,
-                         self._gbuf(cs).data_ptr(), B, cs.H, cs.W, fst)
+                         self._gbuf(cs).data_ptr(), cs.first_wpart.data_ptr(), cs.first_wpart.numel(), B, cs.H, cs.W, fst)
                     call('ssp_unpack_grad', self._gbuf(cs).data_ptr(), gw.data_ptr(), cs.cout, cs.cin, cs.cinp, cs.k, fst)
                     out_grads[id(cs.conv.weight)] = gw
                     if self.reducer is not None:

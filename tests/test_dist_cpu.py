@@ -88,3 +88,140 @@ def test_reducer_is_inert_for_one_rank():
     red.layer_done(flat, 0, 16)
     red.all_reduce()
     assert torch.equal(flat, torch.ones(16)) and not red.active
+
+
+# ---- world size 8: the bucket boundaries and the tail rule of the REAL model's gradient layout (bench.py --gpus 8) ----
+def _yolo_pose_layout():
+    """(lo, hi) of every conv block's slice of the flat gradient buffer, in backward order - engine.Plan.grad_layout's rule
+    (weight | bias  or  weight | bn.weight | bn.bias, each padded to 4 floats) applied to cfg/yolo-pose.cfg."""
+    from helpers import ROOT
+    from singleshotpose_amd.cfg import layer_shapes, parse_cfg
+    blocks = parse_cfg(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    shapes = layer_shapes(blocks, 416, 416)
+    pad4 = lambda n: (n + 3) // 4 * 4
+    sizes = []
+    cin = 3
+    chans = []
+    for ind, b in enumerate(blocks[1:]):
+        w, h, c = shapes[ind]
+        if b['type'] == 'convolutional':
+            prev = 3 if ind == 0 else chans[ind - 1]
+            k = int(b['size'])
+            n = pad4(c * prev * k * k) + (pad4(c) * 2 if int(b['batch_normalize']) else pad4(c))
+            sizes.append((ind, n))
+        chans.append(c)
+    out, off = [], 0
+    for ind, n in sorted(sizes, reverse=True):
+        out.append((off, off + n))
+        off += n
+    return out, off
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from singleshotpose_amd.dist import GradReducer, init_distributed
+    import torch.distributed as dist
+    init_distributed('gloo')
+    layout, total = _yolo_pose_layout()
+    scale = 64                                   # the test moves 1/64 of every slice (0.8 M floats per rank, not 50 M)
+    lay = [(lo // scale // 4 * 4, hi // scale // 4 * 4) for lo, hi in layout]
+    lay = [(lay[i - 1][1] if i else 0, hi) for i, (lo, hi) in enumerate(lay)]
+    n = lay[-1][1]
+    red = GradReducer(None, world, bucket_bytes=(32 << 20) // scale, tail_bytes=(4 << 20) // scale)
+    flat = torch.full((n,), float(rank + 1))
+    flat[::7] = float(rank) * 0.5
+    local = flat.clone()
+    red.begin(flat)
+    for lo, hi in lay:
+        red.layer_done(flat, lo, hi)
+    red.all_reduce()
+    q.put((rank, local.numpy().copy(), flat.numpy().copy(), list(red.launched), n, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_eight_ranks_bucket_boundaries_of_the_real_layout():
+    """SURVEY.md section 8(e) at the world size the metric is quoted on: 8 ranks (gloo, CPU), yolo-pose.cfg's own gradient
+    layout (scaled down 64 x so that the test moves megabytes, not 1.6 GB): SUM over the 8 ranks, identical buckets on every
+    rank, contiguous and covering the buffer, six of them - five closed by the 32 MB rule while the 13 x 13 and 26 x 26
+    layers finish, the small one for layers 0 - 10 by the tail rule (47 / 38 / 38 / 40 / 36 / 3 MB)."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda g: g[0])
+    expected = sum(g[1].astype(np.float64) for g in got)
+    assert got[0][5] >= 50547764                 # the real buffer: every parameter of yolo-pose.cfg (SURVEY.md appendix A), slices padded to 4
+    for g in got:
+        assert np.allclose(g[2], expected, rtol=0, atol=1e-5)
+        assert g[3] == got[0][3]
+    buckets, n = got[0][3], got[0][4]
+    assert buckets[0][0] == 0 and buckets[-1][1] == n and all(b[1] == c[0] for b, c in zip(buckets, buckets[1:]))
+    sizes_mb = [(hi - lo) * 4 * 64 / 2 ** 20 for lo, hi in buckets]
+    assert len(buckets) == 6, sizes_mb
+    assert all(s >= 31.5 for s in sizes_mb[:-1]) and sizes_mb[-1] <= 4.2, sizes_mb
+
+
+def _worker_sync(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from singleshotpose_amd.dist import init_distributed, sync_plans
+    import torch.distributed as dist
+    init_distributed('gloo')
+
+    class M(object):
+        pass
+    m = M()
+    fn = sync_plans(m)
+    assert m._plan_sync is fn
+    out = fn([64, 416, 416, 0, 3, 8006413 + rank, 6413, 12813 * (rank + 1)])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_plans_broadcasts_rank0_codes():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sync, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0] == out[1] == [64, 416, 416, 0, 3, 8006413, 6413, 12813]
+
+
+def test_sync_plans_is_a_noop_without_a_process_group():
+    from singleshotpose_amd.dist import sync_plans
+
+    class M(object):
+        pass
+    m = M()
+    assert sync_plans(m) is None and m._plan_sync is None
+
+
+def test_bench_refuses_to_measure_one_rank_as_many():
+    """`python bench.py --gpus 8` without a launcher: on a node without 8 GPUs nothing is measured and the status is non-zero
+    (with them it re-executes itself under torch.distributed.run, one rank per GPU)."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return
+    assert p.returncode != 0 and 'nothing measured' in p.stdout, p.stdout[-500:]
+    assert '"metric"' not in p.stdout

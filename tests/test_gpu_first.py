@@ -74,10 +74,16 @@ def test_first_block_forward_and_backward(B, H, W):
               vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), 0.1, partial.data_ptr(), B, H, W, st)
     _lib.call('ssp_bn_bwd_finalize', partial.data_ptr(), groups, 32, M, 1, 0, vec[6].data_ptr(), vec[7].data_ptr(),
               vec[4].data_ptr(), vec[5].data_ptr(), st)
-    dw = torch.zeros(32 * 36, device=G.dev())
+    dw = torch.full((32 * 36,), float('nan'), device=G.dev())      # written, not accumulated (ABI 4): NaN-poisoned
+    wsn = _lib.query('ssp_first_wgrad_workspace_floats', B, H, W)
+    wsp = torch.full((wsn,), float('nan'), device=G.dev())
     _lib.call('ssp_first_bwd_wgrad', xdev.data_ptr(), wdev.data_ptr(), gdev_p.data_ptr(), ldo, vec[2].data_ptr(),
               vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), 0.1,
-              dw.data_ptr(), B, H, W, st)
+              dw.data_ptr(), wsp.data_ptr(), wsn, B, H, W, st)
+    with pytest.raises(_lib.SspError, match="workspace"):
+        _lib.call('ssp_first_bwd_wgrad', xdev.data_ptr(), wdev.data_ptr(), gdev_p.data_ptr(), ldo, vec[2].data_ptr(),
+                  vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), 0.1,
+                  dw.data_ptr(), wsp.data_ptr(), wsn - 1, B, H, W, st)
     torch.cuda.synchronize()
     assert rel_err(vec[6].cpu().numpy(), gd.grad.numpy()) < TOL            # dgamma
     assert rel_err(vec[7].cpu().numpy(), bd.grad.numpy()) < TOL            # dbeta

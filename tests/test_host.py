@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libssp_hip.so does not export %s" % name
     # the ctypes table covers the whole header and nothing else
     assert sorted(_lib.exported_symbols()) == declared
-    assert _lib.query('ssp_abi_version') == 3
+    assert _lib.query('ssp_abi_version') == 4
     with pytest.raises(_lib.SspError, match="unknown option"):
         _lib.call('ssp_set_option', b'no_such_knob', 1)
 
