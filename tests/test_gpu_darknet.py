@@ -20,7 +20,26 @@ def _build(cfgfile, seed):
     return model.cuda(), state
 
 
-def _check(cfgfile, tag, B, H, W, seed, with_grad, envelope=3.0):
+def _grad_stats(model, g):
+    """Per-parameter distances to the golden's FLOAT64 gradients: (norm error, element error) of the product and of the
+    reference's own fp32 run."""
+    dn_mine, dn_ref, de_mine, de_ref = [], [], [], []
+    for n, p in model.named_parameters():
+        gr = p.grad.detach().cpu().numpy()
+        n64, n32 = float(g['g64norm/' + n][0]), float(g['gnorm/' + n][0])
+        got_norm = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+        if 'g64/' + n in g.files:
+            ref64, ref32, mine = g['g64/' + n], g['grad/' + n], gr
+        else:
+            ref64, ref32 = g['g64slice/' + n], g['gslice/' + n]
+            k = len(ref64)
+            mine = gr.reshape(-1)[:: max(1, gr.size // k)][:k]
+        dn_mine.append(abs(got_norm / n64 - 1)); dn_ref.append(abs(n32 / n64 - 1))
+        de_mine.append(rel_err(mine, ref64)); de_ref.append(rel_err(ref32, ref64))
+    return dn_mine, dn_ref, de_mine, de_ref
+
+
+def _check(cfgfile, tag, B, H, W, seed, with_grad, envelope=3.0, collect=None):
     g = gold('darknet_%s.npz' % tag)
     model, state = _build(cfgfile, seed)
     x = torch.from_numpy(golden_input(g, B, H, W)).cuda()
@@ -39,22 +58,15 @@ def _check(cfgfile, tag, B, H, W, seed, with_grad, envelope=3.0):
     # elements) away from exact arithmetic: rounding flips max-pool / leaky decisions and the flips propagate.  The
     # golden file therefore also holds the reference run in float64; the GPU path must sit inside the same envelope
     # around the float64 gradients as the reference's fp32 path does (per parameter <= 3x the reference's worst
-    # parameter, and on average no worse than 2.5x the reference's average: the MFMA accumulates each output in one
-    # k-ordered fp32 chain of up to 11520 terms where oneDNN on the CPU sums blocked partials, so slightly more
-    # decisions flip).  Per-kernel and small-net tests keep the
+    # parameter, and on average no worse than 2.5x the reference's average).  Per-kernel and small-net tests keep the
     # strict 1e-4 / 3e-4 bars.
-    dn_mine, dn_ref, de_mine, de_ref = [], [], [], []
-    for n, p in model.named_parameters():
-        gr = p.grad.detach().cpu().numpy()
-        n64, n32 = float(g['g64norm/' + n][0]), float(g['gnorm/' + n][0])
-        got_norm = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
-        if 'g64/' + n in g.files:
-            ref64, ref32, mine = g['g64/' + n], g['grad/' + n], gr
-        else:
-            ref64, ref32 = g['g64slice/' + n], g['gslice/' + n]
-            mine = gr.reshape(-1)[:: max(1, gr.size // 512)][:512]
-        dn_mine.append(abs(got_norm / n64 - 1)); dn_ref.append(abs(n32 / n64 - 1))
-        de_mine.append(rel_err(mine, ref64)); de_ref.append(rel_err(ref32, ref64))
+    dn_mine, dn_ref, de_mine, de_ref = _grad_stats(model, g)
+    for n, b in model.named_buffers():
+        if 'running' in n:
+            np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5)
+    if collect is not None:      # multi-seed statistic: the caller pools the batches
+        collect.append((dn_mine, dn_ref, de_mine, de_ref))
+        return
     if max(de_ref) < 1e-4:      # small nets: no flips, strict bar
         assert max(de_mine) < 3e-4 and max(dn_mine) < 3e-4, (max(de_mine), max(dn_mine))
     else:
@@ -62,9 +74,6 @@ def _check(cfgfile, tag, B, H, W, seed, with_grad, envelope=3.0):
             (max(dn_mine), max(dn_ref), max(de_mine), max(de_ref))
         assert np.mean(dn_mine) <= 2.5 * np.mean(dn_ref) + 1e-5 and np.mean(de_mine) <= 2.5 * np.mean(de_ref) + 1e-5, \
             (np.mean(dn_mine), np.mean(dn_ref), np.mean(de_mine), np.mean(de_ref))
-    for n, b in model.named_buffers():
-        if 'running' in n:
-            np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5)
 
 
 def test_tiny_matches_reference():
@@ -75,17 +84,34 @@ def test_full_eval_matches_reference():
     _check(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 'full_eval', 1, 416, 416, 6, False)
 
 
+FULL_TRAIN_GOLDENS = ('full_train', 'full_train_s211', 'full_train_s212', 'full_train_s213', 'full_train_s214')
+
+
 @pytest.mark.parametrize("tuned", [False, True])
 def test_full_train_matches_reference(monkeypatch, tuned):
-    """Un-frozen whole-network gradients against the reference's own golden run: a STATISTICAL bound (which near-tie
-    max-pool / leaky decisions flip depends on every rounding upstream).  With the library's default plans (direct kernels:
-    a deterministic launch set) the product stays within 3x the reference's own fp32-vs-float64 envelope; with the
-    autotuner's plans - Winograd F(4x4) on most 3x3 layers, about twice the direct kernel's rounding per launch, and a
-    plan set that depends on the box's timings - a few more decisions flip (measured 3.1x on one box of three) and the
-    bound is 5x.  The rigorous check of the tuned path is the decision-frozen one (tests/test_gpu_fullsize.py, 1e-4)."""
+    """Un-frozen whole-network gradients against the reference's own golden runs: a STATISTICAL bound - which near-tie
+    max-pool / leaky decisions flip depends on every rounding upstream, and ONE flipped element that happens to carry a
+    channel's gradient moves that parameter by 1e-3.  So the statistic is taken over FIVE input batches (the same seeded
+    weights; oracle/gen_golden.py gen_multiseed holds the reference's float32 and float64 runs of each), pooled on both
+    sides: the product's worst parameter over the five batches against 3x the reference's own worst (norms and elements),
+    its average against 2.5x the reference's average - with the library's default plans (direct kernels) and with the
+    autotuner's (Winograd F(4x4) on most 3x3 layers, the forward codes admitted under the head-error budget).  Round 4
+    judged this on one batch and had to allow the tuned path 5x (3.1x measured on one box of three); the chunked
+    accumulation of round 5 and the error budget brought the kernels' own rounding down, the five-batch statistic takes
+    the single-flip noise out - the bound is 3x for both.  The rigorous check of the tuned path stays the decision-frozen
+    one (tests/test_gpu_fullsize.py)."""
     if not tuned:
         monkeypatch.setenv('SSP_AUTOTUNE', '0')
-    _check(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 'full_train', 2, 416, 416, 7, True, envelope=5.0 if tuned else 3.0)
+    rows = []
+    for tag in FULL_TRAIN_GOLDENS:
+        _check(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), tag, 2, 416, 416, 7, True, collect=rows)
+    dn_mine, dn_ref, de_mine, de_ref = ([v for r in rows for v in r[k]] for k in range(4))
+    per_batch = [(max(r[0]) / max(r[1]), max(r[2]) / max(r[3])) for r in rows]
+    print('whole-network gradients over %d batches: worst norm error %.2e (reference %.2e), worst element error %.2e '
+          '(reference %.2e); per batch (norm ratio, element ratio): %s' % (
+              len(rows), max(dn_mine), max(dn_ref), max(de_mine), max(de_ref), [(round(a, 2), round(b, 2)) for a, b in per_batch]))
+    assert max(dn_mine) <= 3.0 * max(dn_ref) and max(de_mine) <= 3.0 * max(de_ref), per_batch
+    assert np.mean(dn_mine) <= 2.5 * np.mean(dn_ref) + 1e-5 and np.mean(de_mine) <= 2.5 * np.mean(de_ref) + 1e-5
 
 
 def test_layerwise_vs_oracle_other_resolution():

@@ -190,3 +190,59 @@ def _run_two_ranks(backend):
     sopt.step()
     for sp, got in zip(shadow, a['params_after']):
         assert rel_err(got.numpy(), sp.detach().numpy()) < 1e-6
+
+
+def _sync_worker(rank, world, port, q):
+    """Two ranks on cuda:0 (gloo): rank 1 runs with the autotuner OFF (every plan code 0), rank 0 tunes.  With
+    dist.sync_plans installed both must end up on rank 0's codes - forward, data gradient and the filter gradients' choice."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if rank == 1:
+        os.environ['SSP_AUTOTUNE'] = '0'
+    torch.cuda.set_device(0)
+    from oracle.darknet_ref import seeded_state
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.dist import GradReducer, init_distributed, sync_plans
+    from singleshotpose_amd.region_loss import RegionLoss
+    init_distributed('gloo')
+    from helpers import ROOT
+    # the full network (the tiny cfg's layers are below the tuner's thresholds: nothing to agree on), small input
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 77))
+    model = model.cuda().train()
+    red = GradReducer(model, world)
+    assert sync_plans(model) is not None
+    rs = np.random.RandomState(100 + rank)
+    x = torch.from_numpy(rs.uniform(0, 1, (4, 3, 160, 160)).astype(np.float32)).cuda()
+    tgt = torch.from_numpy(make_targets(rs, 4, [1] * 4))
+    crit = RegionLoss()
+    crit.verbose = False
+    crit(model(x), tgt, 20).backward()
+    red.all_reduce()
+    torch.cuda.synchronize()
+    plan = list(model._plans.values())[0]
+    codes = [(i, cs.plan_fwd, cs.plan_dgrad, getattr(cs, 'wgrad_wino', 0)) for i, cs in sorted(plan.convs.items())]
+    flat = plan.last_flat_grad.cpu().numpy().copy()
+    q.put((rank, codes, bool(np.isfinite(flat).all()), flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_plans_every_rank_runs_rank0_plan_set():
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (c, ok, f) for r, c, ok, f in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert any(f or d for _, f, d, _w in res[1][0]), "rank 0 tuned nothing: the test would pass vacuously"
+    assert res[0][1] and res[1][1]
+    assert np.array_equal(res[0][2], res[1][2])          # the reduced gradient, identical on both ranks
