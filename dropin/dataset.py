@@ -54,7 +54,13 @@ class RawSample(object):
 
 
 class RawBatch(object):
-    """The samples of one DataLoader batch; `.cuda()` is the augmentation."""
+    """The samples of one DataLoader batch; `.cuda()` is the augmentation.
+
+    Built by the collate function - in the worker process when the DataLoader has workers - which packs the decoded bytes
+    of all samples (image, mask, background each) into ONE contiguous uint8 tensor plus an offset table: the batch crosses
+    the worker boundary as one shared-memory segment (one file descriptor, not 3 x batch of them: 64 samples x 10 workers x
+    prefetch 2 was ~3.9 k descriptors, over the usual 1024 limit), `pin_memory()` pins one block, and `.cuda()` is one
+    host-to-device copy followed by the four augmentation launches on views of the device copy."""
 
     def __init__(self, samples):
         shapes = set(s.shape for s in samples)
@@ -62,20 +68,40 @@ class RawBatch(object):
             raise RuntimeError("samples of one batch carry different network shapes %s: the DataLoader's batch_size and "
                                "listDataset's batch_size must agree (dataset.py:66 draws the shape every batch_size "
                                "samples)" % sorted(shapes))
-        self.samples = list(samples)
         self.shape = samples[0].shape
+        self.draws = [s.draws for s in samples]
+        self.layout, off = [], 0                  # per sample: ((offset, h, w) of image, mask, background)
+        for s in samples:
+            row = []
+            for t in (s.img, s.mask, s.bg):
+                if not (t.dtype == torch.uint8 and t.dim() == 3 and t.size(2) == 3):
+                    raise ValueError("decoded images are (h, w, 3) uint8 tensors")
+                row.append((off, int(t.size(0)), int(t.size(1))))
+                off += (t.numel() + 15) // 16 * 16
+            self.layout.append(tuple(row))
+        self.blob = torch.empty(off, dtype=torch.uint8)
+        for s, row in zip(samples, self.layout):
+            for t, (o, h, w) in zip((s.img, s.mask, s.bg), row):
+                self.blob[o:o + h * w * 3] = t.reshape(-1)
+
+    def _views(self, blob):
+        return [tuple(blob[o:o + h * w * 3].view(h, w, 3) for o, h, w in row) for row in self.layout]
+
+    @property
+    def samples(self):
+        """The batch as RawSample views of the packed bytes (introspection / tests)."""
+        return [RawSample(i, m, b, self.shape, d) for (i, m, b), d in zip(self._views(self.blob), self.draws)]
 
     def __len__(self):
-        return len(self.samples)
+        return len(self.layout)
 
     def size(self, dim=None):
         w, h = self.shape
-        full = (len(self.samples), h, w, 3)
+        full = (len(self.layout), h, w, 3)
         return full if dim is None else full[dim]
 
     def pin_memory(self, device=None):
-        for s in self.samples:
-            s.img, s.mask, s.bg = s.img.pin_memory(), s.mask.pin_memory(), s.bg.pin_memory()
+        self.blob = self.blob.pin_memory()        # one pinned block; .cuda() copies straight out of it
         return self
 
     def cuda(self, device=None, non_blocking=False):
@@ -86,11 +112,12 @@ class RawBatch(object):
             idx = torch.cuda.current_device() if idx is None else idx
         dev = torch.device('cuda', idx)
         aug = _augmenter(dev)
-        s = self.samples
         none = np.zeros((0, 1))      # the labels were filled sample by sample in __getitem__
-        out, _ = aug.load_data_detection_batch([x.img.numpy() for x in s], [x.mask.numpy() for x in s],
-                                               [x.bg.numpy() for x in s], [none] * len(s), self.shape, JITTER, HUE,
-                                               SATURATION, EXPOSURE, draws=[x.draws for x in s])
+        with torch.cuda.device(dev):
+            views = self._views(self.blob.to(dev, non_blocking=True))      # ONE upload (asynchronous when the blob is pinned)
+            out, _ = aug.load_data_detection_batch([v[0] for v in views], [v[1] for v in views], [v[2] for v in views],
+                                                   [none] * len(views), self.shape, JITTER, HUE, SATURATION, EXPOSURE,
+                                                   draws=self.draws)
         if os.environ.get('SSP_DATASET_FLOAT', '0') == '1':      # ToTensor's own layout and arithmetic
             return out.permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous()
         return out
@@ -102,6 +129,8 @@ class RawBatch(object):
         return self.cuda(dev)
 
     def __getattr__(self, name):      # anything a tensor would answer
+        if name in ('blob', 'layout', 'draws', 'shape'):      # (un-pickling looks attributes up before __init__ ran)
+            raise AttributeError(name)
         raise AttributeError("dataset.RawBatch has no %r: it is the un-augmented batch - call .cuda() first "
                              "(train.py:82-83), the augmentation runs on the GPU (no CPU fallback)" % name)
 

@@ -372,11 +372,6 @@ class Plan(object):
         self.consumed = False
         self._graph = self._graph_key = self._x_static = self._y_static = None
         self._graph_failed = False
-        self._sg_fwd = self._sg_bwd = None      # (key, graph, state) of the captured training forward / backward chains
-        self._sg_warm = 0
-        self._sg_failed = False
-        self._sg_fwd_live = False
-        self._sg_serial = False      # SSP_STEP_GRAPH=2: the captured chains run on one stream
 
     def _size_layer(self, cs):
         """Statistics / split-K bookkeeping of one conv block for its CURRENT forward plan code (after tuning, and again
@@ -1048,32 +1043,13 @@ class Plan(object):
             call('ssp_u8hwc_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, H, W, self.in_c, self.in_cp, self.in_cp, st)
         else:
             call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
-        # Everything between the two layout conversions is a fixed chain of launches on plan-owned buffers: small training
-        # steps (the cfg's own batch 8: ~300 launches of a few microseconds each, host-bound) replay it from a hipGraph
-        self._sg_fwd_live = False
         if training and need_grad and not self._head_budget_done:
             self._apply_head_budget()        # once per plan, on its first training batch (network-level rounding budget)
             self._sync_codes(0)              # multi-GPU: every rank runs rank 0's forward codes
-        if self._step_graph_mode(training, need_grad, inline_repack):
-            key = self._sg_key()
-            if self._sg_fwd is not None and self._sg_fwd[0] == key:
-                self._sg_fwd[1].replay()
-                self._sg_restore(self._sg_fwd[2])
-                self._sg_fwd_live = True
-            elif self._sg_warm >= 2:
-                try:
-                    g = self._sg_capture(lambda: self._forward_body(training, need_grad, False, join_side=True))
-                    self._sg_fwd = (key, g, self._sg_state())
-                    g.replay()
-                    self._sg_fwd_live = True
-                except Exception as e:      # capture unsupported here: keep the eager launches
-                    self._sg_fail(e)
-                    self._forward_body(training, need_grad, inline_repack)
-            else:
-                self._sg_warm += 1
-                self._forward_body(training, need_grad, inline_repack)
-        else:
-            self._forward_body(training, need_grad, inline_repack)
+        # (The whole training step as two captured hipGraphs was built and measured in round 4 - profiles/r04_step_graph.txt:
+        # a replayed two-stream chain of ~300 nodes is SLOWER than launching it, 9.1 ms against 6.0 ms at batch 8 - and
+        # removed in round 5: it mirrored this method's host-side state by hand.  Inference keeps its graph, forward_graph.)
+        self._forward_body(training, need_grad, inline_repack)
         o = self.out_act
         y = torch.empty(B, o.C, o.H, o.W, dtype=torch.float32, device=self.device)
         call('ssp_nhwc_to_nchw', o.ptr, y.data_ptr(), B, o.C, o.H, o.W, o.ld, st)
@@ -1082,49 +1058,7 @@ class Plan(object):
         self.generation += 1
         return y
 
-    # ------------------------------------------------------------------ training step as two hipGraphs
-    def _step_graph_mode(self, training, need_grad, inline_repack):
-        """SSP_STEP_GRAPH=1: two-stream chains as captured, =2: the same launches captured on ONE stream (a linear graph);
-        default 0 = eager launches - measured on this runtime (profiles/r04_step_graph.txt): a replayed two-stream chain of
-        ~300 nodes is SLOWER than launching it (batch 8: 9.1 ms against 6.0 ms eager), so nothing takes this path unasked.
-        Never with a gradient reducer attached (collectives stay eager) or while the launch timer is on (its events belong
-        to individual launches)."""
-        if not (training and need_grad) or inline_repack or self.reducer is not None or self._sg_failed:
-            return False
-        mode = os.environ.get('SSP_STEP_GRAPH', '0')
-        if mode not in ('1', '2') or _lib.PROF_MASK[0] != 0:
-            return False
-        self._sg_serial = mode == '2'
-        return True
-
-    def _sg_key(self):
-        return tuple((t.data_ptr(), tuple(t.stride())) for t in self._graph_tensors())
-
-    def _sg_capture(self, fn):
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            fn()
-        return g
-
-    def _sg_fail(self, e):
-        import warnings
-        warnings.warn("hipGraph capture of the training step failed (%s); using eager launches" % (e,))
-        self._sg_failed = True
-        self._sg_fwd = self._sg_bwd = None
-        torch.cuda.synchronize(self.device)
-
-    def _sg_state(self):
-        """Host-side flags a forward body leaves behind (restored after a replay)."""
-        return [(cs, cs.first_live, getattr(cs, 'v_live', False), cs.packed) for cs in self.convs.values()]
-
-    def _sg_restore(self, state):
-        for cs, first_live, v_live, packed in state:
-            cs.first_live, cs.v_live, cs.packed = first_live, v_live, packed
-        self.net._bn_epoch += 1
-        self.dgrad_ready = True      # the captured chain joined the side stream: the data-gradient operands are in place
-
-    def _forward_body(self, training, need_grad, inline_repack, join_side=False):
+    def _forward_body(self, training, need_grad, inline_repack):
         B, H, W = self.B, self.H, self.W
         st = torch.cuda.current_stream().cuda_stream
         call = _lib.call
@@ -1174,8 +1108,7 @@ class Plan(object):
         if stale or need_grad or wino:
             if self.side_stream is None:
                 self.side_stream = _side_stream(self.device)
-            # (SSP_STEP_GRAPH=2, capturing: everything on the capturing stream - a linear chain)
-            side = torch.cuda.current_stream() if (join_side and self._sg_serial) else self.side_stream
+            side = self.side_stream
             side.wait_stream(torch.cuda.current_stream())
             for group in (stale[:4], stale[4:]):
                 for cs, key in group:
@@ -1301,12 +1234,6 @@ class Plan(object):
                 for s in srcs:
                     call('ssp_copy_channels', s.ptr, s.ld, _ptr(out.t, off), out.ld, s.C, B * s.H * s.W, 0, st)
                     off += s.C
-        if join_side and self.side_stream is not None:
-            # captured chain: every forked stream rejoins (the data-gradient operand repacks included)
-            if not self._sg_serial:
-                torch.cuda.current_stream().wait_stream(self.side_stream)
-            if self.dgrad_ready is not None:
-                self.dgrad_ready = True
 
     # ------------------------------------------------------------------ inference as one hipGraph
     def _graph_tensors(self):
@@ -1409,24 +1336,6 @@ class Plan(object):
             self.net._flat_grads[self.device] = (flat, _storage_refs(flat))
         flat.record_stream(self.side_stream)
         self.last_flat_grad = flat
-        # the backward chain of a forward that was replayed from its hipGraph is a fixed launch sequence too
-        if self._sg_fwd_live and not self.serial_backward and self._step_graph_mode(self.was_training, True, False):
-            key = (self._sg_key(), flat.data_ptr())
-            if self._sg_bwd is not None and self._sg_bwd[0] == key:
-                self._sg_bwd[1].replay()
-                for cs in self.convs.values():
-                    cs.v_live = False
-                return {pid: torch.as_strided(flat, shape, stride, off) for pid, shape, stride, off in self._sg_bwd[2]}
-            try:
-                box = {}
-                g = self._sg_capture(lambda: box.update(out=self._backward_body(flat)))
-                out_grads = box['out']
-                self._sg_bwd = (key, g, [(pid, tuple(t.shape), tuple(t.stride()), t.storage_offset())
-                                         for pid, t in out_grads.items()])
-                g.replay()
-                return out_grads
-            except Exception as e:
-                self._sg_fail(e)
         return self._backward_body(flat)
 
     def _backward_body(self, flat):
@@ -1444,11 +1353,9 @@ class Plan(object):
         # Filter gradients run on a second stream: wgrad(l) only needs dY(l) and the saved input activation, so it
         # overlaps the dgrad(l) -> BN-backward(l-1) chain of the main stream and fills the idle CUs of its last wave.
         main = torch.cuda.current_stream()
-        side = main if (self.serial_backward or (self._sg_serial and self._sg_fwd_live)) else self.side_stream
+        side = main if self.serial_backward else self.side_stream
         st2 = side.cuda_stream
-        if self.dgrad_ready is True:
-            pass                                    # the forward chain (a hipGraph) already joined the operand repacks
-        elif self.dgrad_ready is not None:
+        if self.dgrad_ready is not None:
             main.wait_event(self.dgrad_ready)       # dgrad filter repacks were queued during forward
         else:
             self._prepare_backward(tune=False)      # the saved conv outputs are live: no timing / verify launches now

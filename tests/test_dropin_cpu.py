@@ -193,6 +193,11 @@ def test_dropin_dataset_through_worker_processes_and_eval_branch(tmp_path):
             assert type(da).__name__ == 'RawBatch' and da.shape == db.shape and torch.equal(ta, tb)
             assert [s.draws for s in da.samples] == [s.draws for s in db.samples]
             assert all(torch.equal(x.img, y.img) and torch.equal(x.bg, y.bg) for x, y in zip(da.samples, db.samples))
+            # ONE tensor crosses the worker boundary per batch (one shared-memory segment / file descriptor, one pin):
+            # image, mask and background of every sample are views of it
+            assert da.blob.dtype == torch.uint8 and da.blob.dim() == 1 and len(da.layout) == 4
+            base = da.blob.untyped_storage().data_ptr()
+            assert all(t.untyped_storage().data_ptr() == base for x in da.samples for t in (x.img, x.mask, x.bg))
         assert dataset.multiscale_width(0, 2, 8) == 13 and dataset.multiscale_width(159, 2, 8) == 13
 
         class Fixed(object):

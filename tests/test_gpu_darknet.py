@@ -569,58 +569,3 @@ def test_training_trajectory_tracks_oracle():
             assert rel_err(p.detach().cpu().numpy(), q.detach().numpy()) < 1e-5, step
 
 
-@pytest.mark.parametrize("graph_mode", ['1', '2'])
-def test_training_step_graph_replay_matches_eager_launches(monkeypatch, graph_mode):
-    """Opt-in (SSP_STEP_GRAPH=1: two-stream chains, =2: one stream): a training step's forward / backward launch chains
-    replayed from hipGraphs (engine.Plan).  Five steps with a zero learning rate (identical weights, new images and labels
-    every step: the chains are captured on the third and replayed after), then the gradients of the fifth, then two steps with
-    a real learning rate (the replayed chains must see the optimizer's in-place updates): same losses, gradients, parameters
-    and running statistics as the eager launches (1e-5: the filter-gradient kernels' fp32 atomics leave last-bit differences
-    between any two runs; whole trajectories are not compared - they diverge chaotically through the loss's thresholds)."""
-    from singleshotpose_amd.optim import SGD
-    from singleshotpose_amd.region_loss import RegionLoss
-    B = 4
-    rs = np.random.RandomState(11)
-    xs = [torch.from_numpy(rs.uniform(0, 1, (B, 3, 96, 96)).astype(np.float32)).cuda() for _ in range(7)]
-    tgts = [torch.from_numpy(make_targets(rs, B, [1] * B)) for _ in range(7)]
-
-    def run(mode):
-        monkeypatch.setenv('SSP_STEP_GRAPH', mode)
-        model, _ = _build(os.path.join(GOLD, 'tiny-pose.cfg'), 12)
-        model.train()
-        crit = RegionLoss()
-        crit.verbose = False
-        opt = SGD(model.parameters(), lr=0.0, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
-        losses, grads = [], None
-        for i, (x, t) in enumerate(zip(xs, tgts)):
-            if i == 5:
-                for g in opt.param_groups:
-                    g['lr'] = 1e-2 / B
-            opt.zero_grad(set_to_none=True)
-            loss = crit(model(x), t, 20)
-            loss.backward()
-            if i == 4:
-                grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
-            opt.step()
-            losses.append(float(loss.detach()))
-        plan = list(model._plans.values())[0]
-        return model, losses, grads, plan
-
-    m0, l0, g0, p0 = run('0')
-    m1, l1, g1, p1 = run(graph_mode)
-    assert p0._sg_fwd is None and p0._sg_bwd is None
-    assert p1._sg_fwd is not None and p1._sg_bwd is not None and not p1._sg_failed      # captured on the third step, replayed after
-    np.testing.assert_allclose(l1[:6], l0[:6], rtol=1e-5)
-    assert l0[5] != l0[6]                                                               # (the last step saw updated weights)
-    for n in g0:
-        assert rel_err(g1[n], g0[n]) < 1e-5, n
-    np.testing.assert_allclose(l1[6], l0[6], rtol=1e-4)
-    for (n, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
-        assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-4, n
-    for (n, a), (_, b) in zip(m0.named_buffers(), m1.named_buffers()):
-        if 'running' in n:
-            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-4, n
-    # an eval forward after replayed training steps sees the current weights and running statistics
-    m0.eval(); m1.eval()
-    with torch.no_grad():
-        assert rel_err(m1(xs[0]).cpu().numpy(), m0(xs[0]).cpu().numpy()) < 1e-4

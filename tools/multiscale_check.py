@@ -48,8 +48,11 @@ for s in sizes:
     ok = (all(r[k] < 1e-4 for k in ('head', 'loss', 'running', 'conv', 'grad_out')) and
           all(e < (5e-4 if n == '0.weight' else 1e-4) for n, e in r['grad_by_param'].items()))
     ok_all = ok_all and ok
-    print('size %3d B=%d: %s | worst grad %s %.2e | %s (%.1f s)' % (s, B, summarize(r), worst[0], worst[1],
-                                                                  'ok' if ok else 'FAIL', time.time() - t0), flush=True)
+    others = max(e for n, e in r['grad_by_param'].items() if n != '0.weight')
+    hb = (model._plans[(B, s, s, 0)].head_budget or {}) if (B, s, s, 0) in model._plans else {}
+    print('size %3d B=%d: %s | worst grad %s %.2e | first filter %.2e, other params %.2e | budget moved %s | %s (%.1f s)' % (
+        s, B, summarize(r), worst[0], worst[1], r['grad_by_param'].get('0.weight', 0.0), others,
+        [(i, a, b) for i, a, b in hb.get('moved', [])], 'ok' if ok else 'FAIL', time.time() - t0), flush=True)
     rec.append(dict(size=s, batch=B, ok=ok, worst_grad_param=worst[0],
                     tuned_plans=sum(1 for _, f, d in r['plans'] if f or d),
                     **{k: float('%.3g' % r[k]) for k in ('head', 'loss', 'running', 'conv', 'grad_out', 'grad')}))
