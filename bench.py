@@ -235,9 +235,9 @@ def verify_step(model, crit, B, H, W, seed, exact=False):
     x_cpu, tgt = synthetic_batch(B, H, W, seed, 'cpu')
     t0 = time.time()
     r = check_train_step(model, crit, x_cpu, tgt, 20, exact=exact)
-    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 5e-4}   # grad: 1e-4 but for the
-    # first layer's ill-conditioned filter gradient (5e-4 against its float64 re-evaluation), tests/test_gpu_fullsize.py
-    ok = all(r[k] < bars[k] for k in bars) and all(e < 1e-4 for n, e in r['grad_by_param'].items() if n != '0.weight')
+    bars = {'head': 1e-4, 'loss': 1e-4, 'running': 1e-4, 'conv': 1e-4, 'grad_out': 1e-4, 'grad': 1e-4}   # north_star's 1e-4; the
+    # tests assert tighter ones on this batch (tests/test_gpu_fullsize.py: head 5e-5, every gradient 7e-5) - `margin` below
+    ok = all(r[k] < bars[k] for k in bars)
     # yardstick: distance to a float64 evaluation of the same raw-output-frozen network - the product's worst parameter
     # and the fp32 oracle's own (the product must be within 1e-4 or 3x the oracle's distance, parameter by parameter)
     # (--verify-exact: adds ~50 s of float64 CPU work; tests/test_gpu_fullsize.py always runs it)
@@ -252,7 +252,7 @@ def verify_step(model, crit, B, H, W, seed, exact=False):
     det['grad_first_filter'] = float('%.3g' % r['grad_by_param'].get('0.weight', 0.0))
     det['margin'] = {k: round(bars[k] / max(r[k], 1e-30), 1) for k in ('head', 'loss', 'running', 'conv', 'grad_out')}
     det['margin']['grad_other_params'] = round(1e-4 / max(det['grad_other_params'], 1e-30), 1)
-    det['margin']['grad_first_filter'] = round(5e-4 / max(det['grad_first_filter'], 1e-30), 1)
+    det['margin']['grad_first_filter'] = round(1e-4 / max(det['grad_first_filter'], 1e-30), 1)
     det['worst_grad_params'] = [[n, float('%.3g' % e)] for n, e in worst]
     det['conv_worst_layer'] = max(r['conv_by_layer'].items(), key=lambda kv: kv[1])[0] if r.get('conv_by_layer') else None
     det.update(bars={k: v for k, v in bars.items()}, seconds=round(time.time() - t0, 1),

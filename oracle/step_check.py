@@ -214,11 +214,14 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
         seq = model.models[ind]
         mine = seq[0].weight.grad.cpu()
         err = _rel(mine, e['weight'].grad)
-        if err > 1e-4 and ind in tape:
+        first_conv = ind == min(i for i, e_ in enumerate(st_b) if e_ is not None)
+        if (err > 1e-4 or first_conv) and ind in tape:
             # An ill-conditioned filter gradient (the first layer's is sum dx * image with sum dx = 0 exactly and an
             # all-positive image: the terms cancel ~1e3 : 1 at B = 64) - the oracle's OWN fp32 accumulation (oneDNN) sits
             # >1e-4 from the exact sum of its own operands.  Re-evaluate the oracle's gradient from the very same
-            # (input, dL/d raw) tensors in float64 and compare against that: a tighter oracle, not a looser bar.
+            # (input, dL/d raw) tensors in float64 and compare against that: a tighter oracle, not a looser bar.  The first
+            # layer's filter gradient is ALWAYS judged this way (round 5): against the fp32 oracle its "error" read 3e-5 ...
+            # 1e-4 from shape to shape - the oracle's own rounding; against the float64 sum the product sits at ~1e-5.
             x_in, node, pad = tape[ind]
             g64 = torch.nn.grad.conv2d_weight(x_in.detach().double(), e['weight'].shape, node.grad.double(), padding=pad)
             res.setdefault('grad_fp64_oracle', {})['%d.weight' % ind] = dict(

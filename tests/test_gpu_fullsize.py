@@ -22,16 +22,25 @@ TOL = 1e-4
 # element and the winner of every pooling window are the product's own - the fused first block included, re-evaluated for
 # the checker by ssp_first_conv_raw + the product's BN / leaky kernel: oracle/darknet_ref.py forward_ref(raw_override,
 # act_override, pool_override)).
-# Every parameter meets the north-star 1e-4 (measured worst: 7e-5 at batch 64, 9.8e-5 at 832 x 832).  The first layer's
-# filter gradient, sum(dx * image) with sum(dx) = 0 exactly over an all-positive image, cancels ~1e3 : 1 at B = 64 - the
-# fp32 oracle itself (oneDNN) sits 1.4e-3 from the float64 sum of its own operands - and keeps its historical bar of 5e-4
-# against that float64 re-evaluation (it sat at 2e-4 while the first block's decisions were still the oracle's own).
+# Bars (round 5; north_star: 1e-4):
+#   every parameter gradient <= 7e-5           measured worst 2.2e-5 over the 20 multi-scale shapes and the headline batch
+#                                              (profiles/r05_multiscale_parity.txt; round 4: 7.8e-5 / 9.8e-5 at 832 x 832)
+#   the first layer's filter gradient <= 7e-5  against the float64 re-evaluation of the oracle's own operands (sum(dx * image)
+#                                              with sum(dx) = 0 exactly over an all-positive image cancels ~1e3 : 1 - the fp32
+#                                              oracle itself sits ~1e-4 from that sum; the product 0.8e-5 since its workgroup
+#                                              partials are summed in float64, ssp_first_bwd_wgrad ABI 4; round 4: bar 5e-4,
+#                                              measured 6e-5 ... 3e-4)
+#   head <= 5e-5 on the headline batch, <= 7e-5 at the other shapes   (measured 3.9e-5 / <= 5.0e-5: the forward plans are
+#                                              admitted under a network-level rounding budget, engine.Plan._apply_head_budget;
+#                                              ~2.4e-5 of it is the fp32 ORACLE's own distance from float64)
 # History: before the leaky branches were frozen a plan-set-dependent 6.8e-4 showed up on layer 24
 # (tools/plansets/r02i_b64_setC.json replays it): ONE element of that layer sits within fp32 rounding of y = 0, takes the
 # other leaky branch in the oracle's BatchNorm arithmetic than in the product's (scale * raw + shift), and happens to
 # carry most of its channel's gradient.  Both branches are valid fp32 results; the float64 yardstick (below) exposed it.
-GRAD_TOL = 1e-4
-GRAD_TOL_FIRST_FILTER = 5e-4
+GRAD_TOL = 7e-5
+GRAD_TOL_FIRST_FILTER = 7e-5
+HEAD_TOL_HEADLINE = 5e-5
+HEAD_TOL = 7e-5
 
 
 def _report(tag, res):
@@ -41,8 +50,8 @@ def _report(tag, res):
         tag, summarize(res), worst, res.get('grad_fp64_oracle', {}), [(i, f, d) for i, f, d in res['plans'] if f or d]))
 
 
-def _assert_step(res):
-    assert res['head'] < TOL, res['head']
+def _assert_step(res, head_tol=HEAD_TOL):
+    assert res['head'] < head_tol, res['head']
     assert res['loss'] < TOL, (res['loss_gpu'], res['loss_ref'])
     assert res['running'] < TOL, res['running']
     assert res['conv'] < TOL, res['conv_by_layer']
@@ -83,8 +92,14 @@ def test_headline_config_b64_train_step_with_tuned_plans():
     _report('yolo-pose B=64 416', res)
     assert any(f or d for _, f, d in res['plans']), "the autotuner picked no plan: nothing tuned was exercised"
     assert len(engine.TUNE_REJECTED) == n_rej, engine.TUNE_REJECTED[n_rej:]
-    _assert_step(res)
+    _assert_step(res, HEAD_TOL_HEADLINE)
     _assert_exact(res)
+    # the float64 yardstick of the forward pass: the product's head is no further from float64 than 2.5x the fp32 oracle's
+    # own head is (measured 3.3e-5 against 2.4e-5), and the error budget of the forward plans did its work
+    print('head vs float64: product %.2e, fp32 oracle %.2e' % (res['head64'], res['head64_ref']))
+    assert res['head64'] <= max(HEAD_TOL_HEADLINE, 2.5 * res['head64_ref']), (res['head64'], res['head64_ref'])
+    hb = next(iter(model._plans.values())).head_budget
+    assert hb is not None and hb['head_deviation'] <= hb['budget'], hb
 
 
 def test_headline_config_b8_seeded_weights_pretrain_epoch():

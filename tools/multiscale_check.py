@@ -2,7 +2,7 @@
 """Parity sweep of the FULL yolo-pose.cfg over the multi-scale training resolutions (dataset.py:66-90: 224..832 in steps
 of 32) with ONE model, as train.py visits them: every shape's training step through oracle/step_check.py (decision-frozen
 oracle backward) with the bars of tests/test_gpu_fullsize.py - head / loss / running statistics / every conv launch /
-every parameter gradient <= 1e-4 (first layer's filter gradient 5e-4 against its float64 re-evaluation).  Exercises the
+every parameter gradient <= 7e-5 (the first layer's filter gradient against its float64 re-evaluation), head <= 7e-5.  Exercises the
 per-shape plans the autotuner picks (hybrid launches, deep split-K, XCD-ordered wgrad, folded taps).
 
   python tools/multiscale_check.py [sizes, comma separated | all] [batch] [json out]
@@ -45,8 +45,8 @@ for s in sizes:
     if exact:
         w64 = sorted(r['grad64_by_param'].items(), key=lambda kv: -kv[1][0])[:4]
         print('   vs float64 (product, fp32 oracle):', [(k, float('%.3g' % a), float('%.3g' % b)) for k, (a, b) in w64], flush=True)
-    ok = (all(r[k] < 1e-4 for k in ('head', 'loss', 'running', 'conv', 'grad_out')) and
-          all(e < (5e-4 if n == '0.weight' else 1e-4) for n, e in r['grad_by_param'].items()))
+    ok = (r['head'] < 7e-5 and all(r[k] < 1e-4 for k in ('loss', 'running', 'conv', 'grad_out')) and
+          all(e < 7e-5 for n, e in r['grad_by_param'].items()))      # the bars of tests/test_gpu_fullsize.py (round 5)
     ok_all = ok_all and ok
     others = max(e for n, e in r['grad_by_param'].items() if n != '0.weight')
     hb = (model._plans[(B, s, s, 0)].head_budget or {}) if (B, s, s, 0) in model._plans else {}
@@ -61,7 +61,7 @@ if out_path:
     with open(out_path, 'w') as f:
         json.dump(dict(what="cfg/yolo-pose.cfg train step per multi-scale resolution vs oracle/step_check.py "
                             "(decision-frozen backward), one model visiting the shapes in order",
-                       bars=dict(head=1e-4, loss=1e-4, running=1e-4, conv=1e-4, grad_out=1e-4, grad=1e-4,
-                                 grad_first_filter=5e-4),
+                       bars=dict(head=7e-5, loss=1e-4, running=1e-4, conv=1e-4, grad_out=1e-4, grad=7e-5,
+                                 grad_first_filter=7e-5),
                        tune_rejected=[list(map(str, t)) for t in engine.TUNE_REJECTED], shapes=rec), f, indent=1)
 sys.exit(0 if ok_all else 1)
