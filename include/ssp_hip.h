@@ -116,6 +116,12 @@ int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int
  * workspace buffer (both layouts start with V [(tile+2)^2][tiles][Cin]) - so the layer input is transformed once per
  * training step, not twice.  The un-suffixed names = tile 2. */
 int64_t ssp_conv_wgrad_wino_workspace_floats_t(int B, int H, int W, int Cin, int Cout, int tile);
+/* The input transform alone: V[(tile+2)^2][tiles][C] = B^T d B of x [B*H*W][ldx] - for a layer whose FORWARD does not run in
+ * the Winograd domain (or runs another tile size) while its filter gradient does: the engine queues it on the second stream
+ * during the forward pass, into the head of that layer's filter-gradient workspace, and calls ssp_conv_wgrad_wino_t with
+ * x == NULL (an HBM-bound pass under the MFMA-bound forward launches instead of inside the backward pass, where both
+ * streams are busy). */
+int ssp_wino_input_transform_t(const float* x, int ldx, float* V, int B, int H, int W, int C, int tile, void* stream);
 int ssp_conv_wgrad_wino_t(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                           int ldx, int tile, float* workspace, int64_t workspace_floats, void* stream);
 int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout);

@@ -57,6 +57,7 @@ _SIGS = {
     "ssp_first_conv_raw": [P, P, P, I, I, I, I, P],
     "ssp_first_bwd_reduce": [P, P, P, I, P, P, P, P, F, P, I, I, I, P],
     "ssp_first_bwd_wgrad": [P, P, P, I, P, P, P, P, P, P, F, P, P, L, I, I, I, P],
+    "ssp_wino_input_transform_t": [P, I, P, I, I, I, I, I, P],
     "ssp_first_wgrad_workspace_floats": [I, I, I],
     "ssp_colsum": [P, I, L, I, P, P],
     "ssp_pose_errors": [P, I, P, P, P, I, I, P, P],

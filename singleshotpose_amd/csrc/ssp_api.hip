@@ -286,6 +286,9 @@ int ssp_conv_wgrad_wino_t(const float* dy, const float* x, float* dw, int B, int
                           int ldx, int tile, float* workspace, int64_t workspace_floats, void* stream) {
   return ssp_conv_wgrad_wino_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, tile, workspace, workspace_floats, (hipStream_t)stream);
 }
+int ssp_wino_input_transform_t(const float* x, int ldx, float* V, int B, int H, int W, int C, int tile, void* stream) {
+  return ssp_wino_input_launch(x, ldx, V, B, H, W, C, tile, SSP_PROF_WINO_WGRAD, (hipStream_t)stream);
+}
 int64_t ssp_conv_wgrad_wino_workspace_floats(int B, int H, int W, int Cin, int Cout) {
   return ssp_conv_wgrad_wino_ws_floats(B, H, W, Cin, Cout, 2);
 }

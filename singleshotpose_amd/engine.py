@@ -1206,9 +1206,21 @@ class Plan(object):
                     continue
                 ws_t = self.ws
                 cs.v_live = False
-                if (need_grad and wino_tile(cs.plan_fwd) and getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and
-                        os.environ.get('SSP_WINO_SHARE_V', '1') != '0'):
+                share_v = os.environ.get('SSP_WINO_SHARE_V', '1') != '0'
+                if need_grad and wino_tile(cs.plan_fwd) and getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and share_v:
                     ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
+                    cs.v_live = True
+                elif need_grad and getattr(cs, 'wgrad_wino', 0) and share_v and self.side_stream is not None:
+                    # The filter gradient runs in the Winograd domain but this forward launch does not leave its V behind (the
+                    # error budget moved the layer to a direct code, or to the other tile size): the input transform the
+                    # filter gradient needs is queued NOW on the second stream - an HBM-bound pass in the shadow of the
+                    # MFMA-bound forward launches - instead of inside the backward pass, where both streams are busy
+                    # (measured: the two layers the budget moves at 416 x 416 cost 0.3 ms of backward time this way).
+                    wws = self._wino_ws(cs)
+                    ready = torch.cuda.current_stream().record_event()      # the layer's input is complete on the main stream
+                    self.side_stream.wait_event(ready)
+                    call('ssp_wino_input_transform_t', cs.inp.ptr, cs.inp.ld, wws.data_ptr(), B, cs.H, cs.W, cs.cinp,
+                         cs.wgrad_wino, self.side_stream.cuda_stream)
                     cs.v_live = True
                 call('ssp_conv_fwd', cs.inp.ptr, wptr, cs.raw.data_ptr(), bias,
                      cs.stats.data_ptr() if use_stats else None, B, cs.H, cs.W, cs.cinp, cs.cout, cs.inp.ld, cs.ldraw,

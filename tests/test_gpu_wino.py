@@ -252,6 +252,31 @@ def test_wino_wgrad_reuses_the_forward_launch_transformed_input(WINO):
     assert rel_err(gw.cpu().numpy(), w.grad.numpy()) < TOL
 
 
+@pytest.mark.parametrize("tile", [2, 4])
+def test_wino_input_transform_alone_feeds_the_filter_gradient(tile):
+    """ssp_wino_input_transform_t + ssp_conv_wgrad_wino_t(x == NULL): what the engine does for a layer whose forward runs a
+    direct code while its filter gradient runs in the Winograd domain (the transform is queued during the forward pass, on
+    the second stream) - the same gradient, bit for bit, as the launch that transforms x itself (a mosaic-tiled 13 x 13 map)."""
+    G, _lib = _imports()
+    B, H, W, Cin, Cout = 8, 13, 13, 64, 128
+    rs = np.random.RandomState(5)
+    xd = G.to_nhwc(torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32)))
+    dyd = G.to_nhwc(torch.from_numpy(rs.standard_normal((B, Cout, H, W)).astype(np.float32)))
+    wsn = _lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile)
+    res = []
+    for early in (False, True):
+        ws = torch.full((wsn,), float('nan'), dtype=torch.float32, device=G.dev())
+        dw = torch.zeros(Cout * 9 * Cin, dtype=torch.float32, device=G.dev())
+        if early:
+            _lib.call('ssp_wino_input_transform_t', xd.data_ptr(), Cin, ws.data_ptr(), B, H, W, Cin, tile, G.stream())
+        _lib.call('ssp_conv_wgrad_wino_t', dyd.data_ptr(), None if early else xd.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, Cout,
+                  Cin, tile, ws.data_ptr(), wsn, G.stream())
+        torch.cuda.synchronize()
+        res.append(dw.cpu())
+    assert torch.isfinite(res[0]).all() and float(res[0].abs().max()) > 0
+    assert rel_err(res[1].numpy(), res[0].numpy()) < 1e-6      # (the filter-gradient kernel's fp32 atomics: last-bit differences)
+
+
 def test_wino_plan_on_a_shape_it_does_not_fit_is_an_error():
     G, _lib = _imports()
     x = torch.zeros(4 * 4 * 4, 64, device=G.dev())
