@@ -217,6 +217,9 @@ def _budget_record(model):
     for plan in model._plans.values():
         hb = getattr(plan, 'head_budget', None)
         if hb:
+            if hb.get('pinned'):
+                return {"budget": hb['budget'], "pinned": "decisions read from SSP_TUNE_CACHE (measured by the process that wrote it)",
+                        "chosen": {str(i): c for i, c in hb['chosen'].items()}}
             return {"budget": hb['budget'], "head_deviation_of_the_chosen_plans": float('%.3g' % hb['head_deviation']),
                     "moved": [{"layer": i, "from": "F(%dx%d)" % (a, a), "to": ("F(%dx%d)" % (b, b)) if b else "direct"} for i, a, b in hb['moved']],
                     "cost_ms_per_forward": round(hb['cost_ms'], 4),

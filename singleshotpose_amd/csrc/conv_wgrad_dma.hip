@@ -384,6 +384,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(WgradArgs p) {
 #endif
 }
 
+__global__ void __launch_bounds__(256) wgrad_zero_kernel(float4* __restrict__ p, size_t n16) {
+  const float4 z = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+
 template <int BMO, int BNI, int NSLOT = 4, bool FOLD = false, bool BVEC = false>
 static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   constexpr int RA = 16;
@@ -452,9 +457,22 @@ static int launch_wgrad_dma(WgradArgs a, hipStream_t stream) {
   a.chunk_m = (int)chunk;
   if (a.zero_ptr != nullptr) {
     a.store = nsplit == 1 ? 1 : 0;
-    if (!a.store && hipMemsetAsync(a.zero_ptr, 0, a.zero_bytes, stream) != hipSuccess) {
-      ssp_set_error("conv_wgrad_dma: hipMemsetAsync failed");
-      return SSP_ERR_HIP;
+    // (a float4 grid-stride store kernel, not hipMemsetAsync: the runtime's fill kernel moved the 151 - 189 MB of a 13 x 13
+    // layer's transform-domain gradient at 0.8 TB/s - 0.19 ms per launch, three of them per step on the filter-gradient
+    // stream, profiles/r05_timeline_launches.txt - where a plain store loop runs at the HBM write rate)
+    if (!a.store) {
+      const size_t n16 = a.zero_bytes / 16;
+      if (n16 > 0) {
+        const unsigned blocks = (unsigned)((n16 + 1023) / 1024 < 16384 ? (n16 + 1023) / 1024 : 16384);
+        hipLaunchKernelGGL(wgrad_zero_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float4*>(a.zero_ptr), n16);
+        SSP_CHECK_LAUNCH("conv_wgrad_dma(zero)");
+      }
+      if (a.zero_bytes % 16) {
+        if (hipMemsetAsync((char*)a.zero_ptr + n16 * 16, 0, a.zero_bytes % 16, stream) != hipSuccess) {
+          ssp_set_error("conv_wgrad_dma: hipMemsetAsync failed");
+          return SSP_ERR_HIP;
+        }
+      }
     }
   }
   int64_t nwg = a.xcd_order ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;

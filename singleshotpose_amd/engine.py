@@ -51,7 +51,10 @@ _TUNE_CACHE = {}
 # ... and per FAMILY of that launch (0 = direct kernels, 2 / 4 = Winograd F(2x2) / F(4x4)): launch shape -> {family: (fastest code
 # of the family, its time in ms)} - what the error budget of the forward plans chooses from (Plan._apply_head_budget)
 _TUNE_FAMILY = {}
-_HEAD_BUDGET_CACHE = {}        # (plan shape, tag, budget) -> {layer: forward plan code}: a rebuilt plan re-measures nothing
+_HEAD_BUDGET_CACHE = {}        # (plan shape, tag, budget, model) -> record: a rebuilt plan re-measures nothing
+_HEAD_BUDGET_PINNED = {}       # (plan shape, tag, budget) -> {layer: forward plan code}: decisions read from / written to the
+                               # SSP_TUNE_CACHE file - a process started with that file runs the SAME plan set without measuring
+                               # (profiled runs hold training steps only; multi-process jobs can share one file)
 _TUNE_VERIFIED = {}            # launch shape -> the plan code(s) that passed verify-after-tune in this process
 _TUNE_VERIFIED_ALSO = set()    # (launch shape, code) pairs verified besides the chosen one (the other families' fastest codes)
 TUNE_REJECTED = []             # (shape key, plan code) pairs verify-after-tune refused
@@ -69,6 +72,8 @@ def _tune_cache_load():
             for k, v in json.load(f).items():
                 if k.startswith('fam|'):
                     _TUNE_FAMILY.setdefault(tuple(json.loads(k[4:])), {int(f_): (int(c), t) for f_, (c, t) in v.items()})
+                elif k.startswith('budget|'):      # a pinned error-budget decision (layer -> forward code) of a plan shape
+                    _HEAD_BUDGET_PINNED.setdefault(tuple(json.loads(k[7:])), {int(i): int(c) for i, c in v.items()})
                 else:
                     _TUNE_CACHE.setdefault(tuple(json.loads(k)), int(v))
 
@@ -81,6 +86,7 @@ def _tune_cache_save():
         with open(tmp, 'w') as f:
             out = {json.dumps(list(k)): v for k, v in _TUNE_CACHE.items()}
             out.update({'fam|' + json.dumps(list(k)): {str(f_): [c, t] for f_, (c, t) in v.items()} for k, v in _TUNE_FAMILY.items()})
+            out.update({'budget|' + json.dumps(list(k)): {str(i): c for i, c in v.items()} for k, v in _HEAD_BUDGET_PINNED.items()})
             json.dump(out, f, indent=0, sort_keys=True)
         os.replace(tmp, path)
 
@@ -418,7 +424,15 @@ class Plan(object):
         if not cand:
             return
         ckey = (self.B, self.H, self.W, _tune_tag(), budget, id(self.net))
+        pkey = (self.B, self.H, self.W, _tune_tag(), budget)
         rec = _HEAD_BUDGET_CACHE.get(ckey)
+        pinned = _HEAD_BUDGET_PINNED.get(pkey)
+        if rec is None and pinned is not None and _TUNE_CACHE_FILE[0] and all(
+                any(c == pinned.get(cs.ind) for c, _ in cs.fwd_fams.values()) for cs in cand):
+            rec = dict(budget=budget, head_deviation=float('nan'), fastest={cs.ind: cs.plan_fwd for cs in cand}, chosen=dict(pinned),
+                       cost_ms=float('nan'), moved=[(cs.ind, wino_tile(cs.plan_fwd), wino_tile(pinned[cs.ind])) for cs in cand
+                                                    if pinned[cs.ind] != cs.plan_fwd], table={}, pinned=True)
+            _HEAD_BUDGET_CACHE[ckey] = rec
         if rec is None:
             o = self.out_act
             head = lambda: o.t[o.off:o.off + self.B * o.H * o.W * o.ld].clone()
@@ -477,6 +491,9 @@ class Plan(object):
                        moved=moved, table={i: [(f_, c_, None if t_ is None else round(t_, 4), float('%.3g' % d))
                                                for f_, c_, t_, d in rows] for i, rows in table.items()})
             _HEAD_BUDGET_CACHE[ckey] = rec
+            if _TUNE_CACHE_FILE[0]:
+                _HEAD_BUDGET_PINNED[pkey] = dict(rec['chosen'])
+                _tune_cache_save()
         for cs in cand:
             cs.plan_fwd = rec['chosen'].get(cs.ind, cs.plan_fwd)
             self._size_layer(cs)

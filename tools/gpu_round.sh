@@ -41,7 +41,7 @@ print('bench: %.1f images/s %.3f ms/step verified=%s roofline.frac=%s launch_uni
 print('verify:', {k: v.get(k) for k in ('head', 'head64', 'head64_ref', 'conv', 'grad_other_params', 'grad_first_filter', 'worst_grad_params', 'margin')})
 print('kernel_ms_per_step:', d.get('kernel_ms_per_step'))
 hb = d.get('head_budget')
-if hb:
+if hb and not hb.get('pinned'):
     print('head_budget: budget %s chosen deviation %s moved %s cost %.3f ms' % (hb['budget'], hb['head_deviation_of_the_chosen_plans'], hb['moved'], hb['cost_ms_per_forward']))
     for l, rows in sorted(hb['per_layer_candidates'].items(), key=lambda kv: int(kv[0])):
         print('   layer %2s: %s' % (l, ['%s %s ms d=%.2e' % (r['family'], r['ms'], r['head_deviation']) for r in rows]))
