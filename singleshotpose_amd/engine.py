@@ -149,6 +149,36 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+def choose_under_budget(table, budget):
+    """The error-aware choice of Plan._apply_head_budget, as a pure function (tests/test_host.py).
+
+    table: {layer: [(family, plan code, launch ms, head deviation), ...]} - the candidates of every layer, FASTEST FIRST, the
+    direct code (deviation 0 by definition: it is the reference the deviations are measured against) among them.  The
+    deviations of different layers are independent roundings and add in quadrature.  Starting from the fastest candidate
+    everywhere, the layer that buys the most squared deviation per millisecond is moved to its next more accurate candidate
+    until sqrt(sum d^2) <= budget (or nothing is left to move).  Returns ({layer: index into its list}, [(layer, family
+    left, family taken), ...])."""
+    choice = {i: 0 for i in table}
+    moved = []
+    total = lambda: sum(table[i][choice[i]][3] ** 2 for i in table) ** 0.5
+    while total() > budget:
+        best, gain = None, 0.0
+        for i, rows in table.items():
+            k = choice[i]
+            for k2 in range(k + 1, len(rows)):
+                if rows[k2][3] < rows[k][3]:      # the next candidate that is actually more accurate
+                    dt = max((rows[k2][2] or 0.0) - (rows[k][2] or 0.0), 1e-6)
+                    g = (rows[k][3] ** 2 - rows[k2][3] ** 2) / dt
+                    if g > gain:
+                        best, gain = (i, k2), g
+                    break
+        if best is None:
+            break
+        moved.append((best[0], table[best[0]][choice[best[0]]][0], table[best[0]][best[1]][0]))
+        choice[best[0]] = best[1]
+    return choice, moved
+
+
 class _Act(object):
     """A [pixels][ld] fp32 view: tensor + channel offset."""
     __slots__ = ('t', 'off', 'C', 'H', 'W', 'ld')
@@ -467,24 +497,8 @@ class Plan(object):
                     table[cs.ind] = rows
             finally:
                 self.bn_momentum = mom
-            choice = {ind: 0 for ind in table}          # index into table[ind]
+            choice, moved = choose_under_budget(table, budget)
             total = lambda: sum(table[i][choice[i]][3] ** 2 for i in table) ** 0.5
-            moved = []
-            while total() > budget:
-                best, gain = None, 0.0
-                for i, rows in table.items():
-                    k = choice[i]
-                    for k2 in range(k + 1, len(rows)):
-                        if rows[k2][3] < rows[k][3]:
-                            dt = max((rows[k2][2] or 0.0) - (rows[k][2] or 0.0), 1e-6)
-                            g = (rows[k][3] ** 2 - rows[k2][3] ** 2) / dt
-                            if g > gain:
-                                best, gain = (i, k2), g
-                            break
-                if best is None:
-                    break
-                moved.append((best[0], table[best[0]][choice[best[0]]][0], table[best[0]][best[1]][0]))
-                choice[best[0]] = best[1]
             rec = dict(budget=budget, head_deviation=total(), fastest=fastest,
                        chosen={i: table[i][choice[i]][1] for i in table},
                        cost_ms=sum((table[i][choice[i]][2] or 0.0) - (table[i][0][2] or 0.0) for i in table),

@@ -414,3 +414,65 @@ def test_tune_cache_keys_carry_the_candidate_set(monkeypatch):
     monkeypatch.setenv('SSP_WINOGRAD', '0')
     off = engine._tune_tag()
     assert len({both, only2, off}) == 3
+
+
+def test_error_budget_choice_on_the_measured_table():
+    """engine.choose_under_budget on the table the MI355X measured for yolo-pose.cfg at 416 x 416, batch 64
+    (profiles/r05_bench.json head_budget): head deviation of F(4x4) / F(2x2) against the direct code, launch times in ms."""
+    from singleshotpose_amd.engine import choose_under_budget
+    F4 = {4: (0.6308, 3.05e-5), 6: (0.6308, 2.25e-5), 8: (0.4111, 1.96e-5), 10: (0.4111, 1.54e-5), 12: (0.328, 9.79e-6),
+          14: (0.328, 6.25e-6), 16: (0.328, 4.98e-6), 18: (0.3027, 3.92e-6), 20: (0.3027, 2.82e-6), 22: (0.3027, 2.01e-6),
+          23: (0.52, 1.80e-6), 24: (0.52, 1.68e-6), 29: (0.6339, 2.16e-6)}
+    F2 = {8: (0.6752, 9.19e-6), 10: (0.6752, 6.43e-6), 12: (0.477, 4.60e-6), 14: (0.477, 2.84e-6), 16: (0.477, 2.69e-6),
+          18: (0.4512, 1.80e-6), 20: (0.4512, 1.32e-6), 22: (0.4512, 1.04e-6), 23: (0.8425, 7.51e-7), 24: (0.8425, 7.06e-7),
+          29: (1.0249, 5.56e-7)}
+    D = {4: 0.7839, 6: 0.7839, 8: 0.7627, 10: 0.7627, 12: 0.725, 14: 0.725, 16: 0.725, 18: 0.7205, 20: 0.7205, 22: 0.7205,
+         23: 1.392, 24: 1.392, 29: 1.7214}
+    table = {}
+    for i in F4:
+        rows = [(4, 8000000 + i, F4[i][0], F4[i][1])]
+        if i in F2:
+            rows.append((2, 9000000 + i, F2[i][0], F2[i][1]))
+        rows.append((0, 12813, D[i], 0.0))
+        table[i] = rows
+    dev = lambda ch: sum(table[i][ch[i]][3] ** 2 for i in table) ** 0.5
+    ch, moved = choose_under_budget(table, 1e-3)                 # a budget nothing reaches: the fastest code everywhere
+    assert moved == [] and all(k == 0 for k in ch.values()) and 4.5e-5 < dev(ch) < 5.0e-5
+    ch, moved = choose_under_budget(table, 3.5e-5)               # the default: the two 104 x 104 layers go back to the direct code
+    assert moved == [(4, 4, 0), (6, 4, 0)] and dev(ch) <= 3.5e-5
+    ch, moved = choose_under_budget(table, 2.5e-5)               # ... then layer 8 to F(2x2): the cheapest error per millisecond
+    assert moved == [(4, 4, 0), (6, 4, 0), (8, 4, 2)] and dev(ch) <= 2.5e-5
+    ch, moved = choose_under_budget(table, 0.0)                  # nothing but the direct codes meets a zero budget
+    assert all(table[i][ch[i]][0] == 0 for i in table) and dev(ch) == 0.0
+    # a layer without a more accurate candidate cannot be moved: the loop ends instead of spinning
+    ch, moved = choose_under_budget({3: [(4, 1, 0.1, 1e-5)]}, 1e-6)
+    assert ch == {3: 0} and moved == []
+
+
+def test_tune_cache_file_keeps_family_tables_and_budget_decisions(tmp_path, monkeypatch):
+    from singleshotpose_amd import engine
+    path = str(tmp_path / 'tune.json')
+    monkeypatch.setenv('SSP_TUNE_CACHE', path)
+    saved = (dict(engine._TUNE_CACHE), dict(engine._TUNE_FAMILY), dict(engine._HEAD_BUDGET_PINNED), engine._TUNE_CACHE_FILE[0])
+    try:
+        for d in (engine._TUNE_CACHE, engine._TUNE_FAMILY, engine._HEAD_BUDGET_PINNED):
+            d.clear()
+        engine._TUNE_CACHE_FILE[0] = None
+        engine._tune_cache_load()
+        key = ('fwd', 64, 104, 104, 64, 128, 3, 64, 128, True, engine._tune_tag())
+        engine._TUNE_CACHE[key] = 8012813
+        engine._TUNE_FAMILY[key] = {4: (8012813, 0.63), 0: (12813, 0.78)}
+        engine._HEAD_BUDGET_PINNED[(64, 416, 416, engine._tune_tag(), 3.5e-5)] = {4: 12813, 8: 8006413}
+        engine._tune_cache_save()
+        for d in (engine._TUNE_CACHE, engine._TUNE_FAMILY, engine._HEAD_BUDGET_PINNED):
+            d.clear()
+        engine._TUNE_CACHE_FILE[0] = None
+        engine._tune_cache_load()
+        assert engine._TUNE_CACHE[key] == 8012813
+        assert engine._TUNE_FAMILY[key] == {4: (8012813, 0.63), 0: (12813, 0.78)}
+        assert engine._HEAD_BUDGET_PINNED[(64, 416, 416, engine._tune_tag(), 3.5e-5)] == {4: 12813, 8: 8006413}
+    finally:
+        for d, v in zip((engine._TUNE_CACHE, engine._TUNE_FAMILY, engine._HEAD_BUDGET_PINNED), saved[:3]):
+            d.clear()
+            d.update(v)
+        engine._TUNE_CACHE_FILE[0] = saved[3]
