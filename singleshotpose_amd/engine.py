@@ -1241,7 +1241,8 @@ class Plan(object):
                 if need_grad and wino_tile(cs.plan_fwd) and getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and share_v:
                     ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
                     cs.v_live = True
-                elif need_grad and getattr(cs, 'wgrad_wino', 0) and share_v and self.side_stream is not None:
+                elif (need_grad and getattr(cs, 'wgrad_wino', 0) and share_v and self.side_stream is not None and
+                        os.environ.get('SSP_WINO_EARLY_V', '1') != '0'):
                     # The filter gradient runs in the Winograd domain but this forward launch does not leave its V behind (the
                     # error budget moved the layer to a direct code, or to the other tile size): the input transform the
                     # filter gradient needs is queued NOW on the second stream - an HBM-bound pass in the shadow of the

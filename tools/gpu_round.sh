@@ -9,7 +9,7 @@
 #   smoke        __graft_entry__.smoke()
 #   bench        the driver's command: python bench.py --steps 20 --warmup 5       (BENCH_ARGS adds flags)
 #   benchq       the same without extras / CPU baseline (verify stays on)          (BENCH_ARGS adds flags)
-#   ab           whole-step A/B on this box, two interleaved rounds: AB_CFGS="-;@acc_chunk=0;SSP_WINOGRAD=0"
+#   ab           whole-step A/B on this box, two interleaved rounds: AB_CFGS="-;@acc_chunk=0;SSP_WINOGRAD=0"  (BENCH_ARGS adds flags)
 #                (a cfg is "-" = defaults, VAR=value environment settings and / or @name=value,... = bench.py --opt)
 #   profile      rocprofv3 --kernel-trace --stats of 1 warm-up + 3 real steps, per-queue timeline (+ launch list) of the last
 #   traffic      rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (own runs, kernel trace only) -> traffic_TAG.json
@@ -78,7 +78,7 @@ for STAGE in "$@"; do
           for tok in $o; do
             case "$tok" in -) ;; @*) a="--opt ${tok#@}" ;; *) e="$e $tok" ;; esac
           done
-          env $e timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-extras $a 2>$OUT/ab_$TAG.err | tail -1 | \
+          env $e timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-extras $BENCH_ARGS $a 2>$OUT/ab_$TAG.err | tail -1 | \
             python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-40s %8.2f img/s %7.3f ms  fwd %.1f TF bwd %.1f TF' % ('$o', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline_bwd']['achieved']), d['kernel_ms_per_step'])" | tee -a $OUT/ab_$TAG.log
         done
       done ;;
