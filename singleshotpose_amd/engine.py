@@ -1242,12 +1242,13 @@ class Plan(object):
                     ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
                     cs.v_live = True
                 elif (need_grad and getattr(cs, 'wgrad_wino', 0) and share_v and self.side_stream is not None and
-                        os.environ.get('SSP_WINO_EARLY_V', '1') != '0'):
+                        os.environ.get('SSP_WINO_EARLY_V', '0') == '1'):
                     # The filter gradient runs in the Winograd domain but this forward launch does not leave its V behind (the
                     # error budget moved the layer to a direct code, or to the other tile size): the input transform the
-                    # filter gradient needs is queued NOW on the second stream - an HBM-bound pass in the shadow of the
-                    # MFMA-bound forward launches - instead of inside the backward pass, where both streams are busy
-                    # (measured: the two layers the budget moves at 416 x 416 cost 0.3 ms of backward time this way).
+                    # filter gradient needs CAN be queued now on the second stream (SSP_WINO_EARLY_V=1) - an HBM-bound pass next
+                    # to the forward launches instead of inside the backward pass.  Measured on one box, two interleaved rounds
+                    # (profiles/r05_step_ab.txt): 27.48 / 27.57 ms with it, 27.38 / 27.47 without - the transform slows the
+                    # MFMA-bound direct launches it runs beside by as much as it saves later; off by default.
                     wws = self._wino_ws(cs)
                     ready = torch.cuda.current_stream().record_event()      # the layer's input is complete on the main stream
                     self.side_stream.wait_event(ready)
