@@ -225,3 +225,22 @@ def test_bench_refuses_to_measure_one_rank_as_many():
         return
     assert p.returncode != 0 and 'nothing measured' in p.stdout, p.stdout[-500:]
     assert '"metric"' not in p.stdout
+
+
+def test_launch_dp_script_starts_one_process_per_rank_with_the_queue_setting(tmp_path):
+    """tools/launch_dp.sh N script: N ranks through torch.distributed.run on 127.0.0.1, GPU_MAX_HW_QUEUES=8 and the dmabuf IPC
+    mode exported BEFORE the ranks start."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    probe = tmp_path / 'probe.py'
+    # (one file per rank: two processes printing to one pipe interleave their lines)
+    probe.write_text("import os\nopen(os.path.join(%r, 'rank' + os.environ['RANK']), 'w').write(' '.join([os.environ['RANK'], "
+                     "os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], str(os.environ.get('GPU_MAX_HW_QUEUES')), "
+                     "str(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))]))\n" % str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'GPU_MAX_HW_QUEUES', 'MASTER_PORT')}
+    p = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'launch_dp.sh'), '2', str(probe)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1000:]
+    rows = [open(str(tmp_path / ('rank%d' % r))).read().split() for r in range(2)]
+    assert rows == [['0', '2', '127.0.0.1', '8', '0'], ['1', '2', '127.0.0.1', '8', '0']], rows
