@@ -16,7 +16,7 @@
 #   pmcconv      MFMA / LDS counters of single conv launches: PMC_CASES=l9,l18 PMC_OPS=fwd,dgrad PMC_PLANS=0,8006413
 #   convbench    tools/conv_bench.py $CONVBENCH_ARGS  (single-layer timings / errors through the C ABI)
 #   multiscale   tools/multiscale_check.py $MULTISCALE_ARGS   (default: all 8)
-#   soak         tools/soak.py $SOAK_ARGS
+#   soak         tools/soak.py $SOAK_ARGS   (default: 1000 steps -> gpurun_out/soak_TAG.json)
 #   run          $RUN_CMD (anything else, logged to run_TAG.log)
 # The bench stages write the timed plan choices to gpurun_out/tune_cache_TAG.json; the profiled stages reuse them, so their
 # traces hold training steps only.
@@ -113,8 +113,8 @@ for STAGE in "$@"; do
       timeout 1500 python tools/multiscale_check.py ${MULTISCALE_ARGS:-all 8} > $OUT/multiscale_$TAG.txt 2>&1
       tail -30 $OUT/multiscale_$TAG.txt ;;
     soak)
-      timeout 1500 python tools/soak.py $SOAK_ARGS > $OUT/soak_$TAG.json 2> $OUT/soak_$TAG.err
-      tail -5 $OUT/soak_$TAG.json ;;
+      timeout 1500 python tools/soak.py ${SOAK_ARGS:-1000 $OUT/soak_$TAG.json} > $OUT/soak_$TAG.log 2> $OUT/soak_$TAG.err
+      head -c 600 $OUT/soak_$TAG.log ;;
     run)
       timeout ${RUN_SECONDS:-900} bash -c "$RUN_CMD" > $OUT/run_$TAG.log 2>&1
       tail -40 $OUT/run_$TAG.log ;;
