@@ -232,3 +232,46 @@ def test_dropin_dataset_through_worker_processes_and_eval_branch(tmp_path):
             os.chdir(cwd)
     finally:
         cleanup()
+
+
+def test_occlusion_fixture_is_what_the_multi_drivers_open(tmp_path):
+    """tests/fixture_occlusion.py: the files train_multi.py / valid_multi.py open, where they look for them (cwd = <root>/multi,
+    '../LINEMOD/...', '../VOCdevkit/...'), the labels_occlusion rows from the golden record, deterministic; and the parsers on
+    the golden's own numbers."""
+    import hashlib
+    import fixture_occlusion as fo
+    gold = json.load(open(os.path.join(GOLD, 'dropin_multi.json')))
+    info = fo.make(str(tmp_path / 'a'))
+    root, cwd = info['root'], info['cwd']
+    assert info['test_images'] == sorted(gold['labels_occlusion']['ape'])
+    for rel in ('cfg/occlusion.data', 'cfg/train_occlusion.txt', 'cfg/yolo-pose-multi.cfg', 'init.weights'):
+        assert os.path.isfile(os.path.join(cwd, rel)), rel
+    for o in fo.VALID:
+        assert os.path.isfile(os.path.join(cwd, 'cfg', '%s_occlusion.data' % o))
+        lines = open(os.path.join(root, 'LINEMOD', o, 'test_occlusion.txt')).read().split()
+        assert len(lines) == 4 and all(os.path.isfile(os.path.join(cwd, l)) for l in lines)
+        for nm in info['test_images']:       # dataset_multi.py:76: benchvise image path -> this object's labels_occlusion row
+            row = np.loadtxt(os.path.join(root, 'LINEMOD', o, 'labels_occlusion', nm + '.txt'))
+            assert row.shape == (21,) and int(row[0]) == fo.CLASS_ID[o]
+            assert np.allclose(row, gold['labels_occlusion'][o][nm], atol=1e-8)
+    for o in fo.PASTED:                     # image_multi.py:320-326: '../LINEMOD/<obj>/train.txt' lines, prefixed with '../'
+        for l in open(os.path.join(root, 'LINEMOD', o, 'train.txt')).read().split():
+            img = os.path.join(cwd, '..', l)
+            assert os.path.isfile(img)
+            assert os.path.isfile(img.replace('JPEGImages', 'mask').replace('/00', '/'))
+            assert os.path.isfile(img.replace('JPEGImages', 'labels').replace('.png', '.txt'))
+    train = open(os.path.join(cwd, 'cfg', 'train_occlusion.txt')).read().split()
+    assert len(train) == 8 and all(os.path.isfile(os.path.join(cwd, l)) for l in train)
+    # deterministic: a second build gives the same scene bytes and the same weights
+    b = fo.make(str(tmp_path / 'b'))
+    for rel in ('LINEMOD/benchvise/JPEGImages/000009.png', 'LINEMOD/cat/mask/0002.png', 'multi/init.weights'):
+        ha, hb = (hashlib.sha1(open(os.path.join(r, rel), 'rb').read()).hexdigest() for r in (root, b['root']))
+        assert ha == hb, rel
+    # the golden record itself: two training batches of four with 8 labels per image, sixty accuracy numbers with a spread
+    assert [s['nGT'] for s in gold['train']['steps']] == [32, 32] and len(gold['train']['steps_one_thread']) == 2
+    assert list(gold['valid']) == list(fo.VALID) and all(len(v) == 10 for v in gold['valid'].values())
+    assert {a for v in gold['valid'].values() for a in v} >= {0.0, 25.0, 50.0, 75.0, 100.0}
+    text = '4: nGT 32, recall 0, proposals 3309, loss: x 168.752808, y 210.650909, conf 349.375793, cls 89.837532, total 469.241241\n' \
+           '2026-09-25 08:05:47 epoch 0, processed 0 samples, lr 0.000100\n2026 Testing ape...\n   Acc using 5 px 2D Projection = 25.00%\n'
+    assert fo.parse_train_output(text)['steps'][0]['loss_cls'] == 89.837532
+    assert fo.parse_valid_output(text) == {'ape': [25.0]}
