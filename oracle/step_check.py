@@ -78,7 +78,8 @@ def _clone(state, requires_grad=False):
     return out
 
 
-def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_backward=True, exact=False):
+def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_backward=True, exact=False,
+                     first_raw_slice_bytes=(1 << 31) - 1):
     """model: product Darknet on the GPU (train mode is set here); crit: product RegionLoss(Multi); x_cpu (B,3,H,W)
     float32 CPU; tgt (B, 50*21) CPU labels.  Returns a dict of errors (see the module docstring) plus 'plans', the
     (layer, forward plan code, dgrad plan code) triples that were active."""
@@ -100,8 +101,13 @@ def check_train_step(model, crit, x_cpu, tgt, epoch, loss_kwargs=None, frozen_ba
             # evaluates it once more with the same instruction sequence (bit-identical values) for this checker.
             from singleshotpose_amd import _lib
             tmp = torch.empty(cs.M * cs.cout, dtype=torch.float32, device=dev)
-            _lib.call('ssp_first_conv_raw', cs.inp.ptr, plan._wbuf(cs).data_ptr(), tmp.data_ptr(), cs.cout, B, cs.H, cs.W,
-                      torch.cuda.current_stream().cuda_stream)
+            # (in batch slices: the entry point addresses its output with 32-bit offsets - 2 GiB per call; batch 64 at 608 x 608 is 3 GB)
+            per = max(1, min(B, first_raw_slice_bytes // (cs.H * cs.W * cs.cout * 4)))
+            for b0 in range(0, B, per):
+                nb = min(per, B - b0)
+                _lib.call('ssp_first_conv_raw', cs.inp.ptr + 4 * b0 * cs.H * cs.W * cs.inp.ld, plan._wbuf(cs).data_ptr(),
+                          tmp.data_ptr() + 4 * b0 * cs.H * cs.W * cs.cout, cs.cout, nb, cs.H, cs.W,
+                          torch.cuda.current_stream().cuda_stream)
             raws[ind] = tmp.view(B, cs.H, cs.W, cs.cout).permute(0, 3, 1, 2).contiguous().cpu()
             first_raw = (ind, tmp)      # kept on the device: its decisions are frozen below like every other pooled block's
             continue

@@ -175,6 +175,28 @@ def test_multiscale_full_network_train_step(size, B):
     _assert_step(res)
 
 
+def test_checker_reads_the_fused_first_block_in_batch_slices():
+    """oracle/step_check.py re-evaluates the fused first block's raw map with ssp_first_conv_raw, whose output offsets are 32-bit
+    (2 GiB per call): batch 64 at 608 x 608 needs two calls.  The slicing, forced here to one image per call on a small
+    batch: the step check (every conv launch against the oracle, layer 0 included) passes as with one call."""
+    from oracle.darknet_ref import seeded_state
+    from oracle.step_check import check_train_step
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.region_loss import RegionLoss
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    load_state_into(model, model.blocks, seeded_state(model.blocks, 5))
+    model = model.cuda()
+    rs = np.random.RandomState(5)
+    B, size = 3, 160
+    x = torch.from_numpy(rs.uniform(0, 1, (B, 3, size, size)).astype(np.float32))
+    tgt = torch.from_numpy(make_targets(rs, B, [1] * B))
+    res = check_train_step(model, RegionLoss(), x, tgt, 20, first_raw_slice_bytes=size * size * 32 * 4)
+    assert next(iter(model._plans.values())).convs[0].first_live
+    _report('sliced first block, B=3 160x160', res)
+    _assert_step(res)
+    assert res['conv_by_layer'][0] < TOL
+
+
 def test_multiscale_schedule_one_model_many_shapes():
     """What train.py does after epoch 10: ONE model, a new resolution every few batches, shapes revisited.  Every visit
     of every shape (first visit = plan build + autotune + verify-after-tune, second visit = cached plan) against the
