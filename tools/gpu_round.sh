@@ -5,7 +5,8 @@
 #
 # Stages (outputs go to gpurun_out/, named *_TAG.*; copy what is to be judged into profiles/):
 #   kernels      the per-kernel parity tests (conv / Winograd / first block / head) - the quick check after a kernel change
-#   tests        the whole `pytest -m gpu` suite              (PYTEST_ARGS="-k multi" narrows it, PYTEST_SECONDS bounds it)
+#   tests        the whole `pytest -m gpu` suite              (PYTEST_PATHS="tests/test_x.py::test_y ..." narrows it, PYTEST_ARGS adds
+#                flags, PYTEST_SECONDS bounds it)
 #   smoke        __graft_entry__.smoke()
 #   bench        the driver's command: python bench.py --steps 20 --warmup 5       (BENCH_ARGS adds flags)
 #   benchq       the same without extras / CPU baseline (verify stays on)          (BENCH_ARGS adds flags)
@@ -59,7 +60,7 @@ for STAGE in "$@"; do
         -m gpu -q -x -rf -p no:cacheprovider $PYTEST_ARGS > $OUT/pytest_kernels_$TAG.log 2>&1
       grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/pytest_kernels_$TAG.log | tail -30 ;;
     tests)
-      timeout ${PYTEST_SECONDS:-1500} python -m pytest tests -m gpu -q -rfs -p no:cacheprovider --durations=15 $PYTEST_ARGS > $OUT/pytest_$TAG.log 2>&1
+      timeout ${PYTEST_SECONDS:-1500} python -m pytest ${PYTEST_PATHS:-tests} -m gpu -q -rfs -p no:cacheprovider --durations=15 $PYTEST_ARGS > $OUT/pytest_$TAG.log 2>&1
       grep -E "^(FAILED|ERROR|SKIPPED)|passed|failed|yolo-pose|^E  " $OUT/pytest_$TAG.log | tail -60 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1
