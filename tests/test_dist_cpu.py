@@ -244,3 +244,61 @@ def test_launch_dp_script_starts_one_process_per_rank_with_the_queue_setting(tmp
     assert p.returncode == 0, p.stdout[-1000:]
     rows = [open(str(tmp_path / ('rank%d' % r))).read().split() for r in range(2)]
     assert rows == [['0', '2', '127.0.0.1', '8', '0'], ['1', '2', '127.0.0.1', '8', '0']], rows
+
+
+def _worker_plan_sync(rank, world, port, q):
+    """Both ranks build the engine's plan of the full network (CPU buffers: no launches), rank 0 carries a tuned-looking code
+    set, rank 1 the library defaults; after Plan._sync_codes both hold rank 0's - and the sizes derived from the codes."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import ROOT
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.dist import init_distributed, sync_plans
+    import torch.distributed as dist
+    init_distributed('gloo')
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    assert sync_plans(model) is not None
+    plan = engine.Plan(model, 4, 160, 160, torch.device('cpu'))
+    for cs in plan.convs.values():
+        cs.plan_dgrad, cs.wgrad_wino = 0, 0
+    before = {i: (cs.tile_m, cs.ntile, cs.ws_fwd, cs.stats.numel() if cs.bn else 0) for i, cs in plan.convs.items()}
+    if rank == 0:
+        plan.convs[8].plan_fwd = 8006413            # F(4x4), 64-row GEMM tiles
+        plan.convs[12].plan_fwd = 9006413           # F(2x2)
+        plan.convs[13].plan_fwd = 12813             # a direct tile choice
+        plan.convs[8].plan_dgrad, plan.convs[8].wgrad_wino = 8006413, 4
+        plan.convs[18].plan_dgrad, plan.convs[18].wgrad_wino = 6413, 2
+        for i in (8, 12, 13):
+            plan._size_layer(plan.convs[i])
+        plan.convs[8].wino_ws_floats = 123
+    plan._sync_codes(0)
+    plan._sync_codes(1)
+    out = {i: (cs.plan_fwd, cs.plan_dgrad, cs.wgrad_wino, cs.tile_m, cs.ntile, cs.ws_fwd, cs.stats.numel() if cs.bn else 0,
+               getattr(cs, 'wino_ws_floats', None) if cs.wgrad_wino else None) for i, cs in plan.convs.items()}
+    q.put((rank, out, before, plan.ws_floats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plan_sync_adopts_rank0_codes_and_resizes():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_plan_sync, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (o, b, w) for r, o, b, w in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0][0], res[1][0]
+    for i in a:      # same codes, same derived sizes (rank 0's own filter-gradient workspace figure aside: it was a dummy)
+        assert a[i][:7] == b[i][:7], (i, a[i], b[i])
+    assert (a[8][0], a[8][1], a[8][2]) == (8006413, 8006413, 4) and a[12][0] == 9006413 and a[13][0] == 12813
+    assert a[18][1:3] == (6413, 2)
+    assert b[8][3] == 0 and b[12][3] == 0                      # Winograd plans: the counted statistics format (tile_m 0)
+    assert b[8][5] > res[1][1][8][2] and res[1][2] >= b[8][5]   # ... a workspace for V | M, and the shared buffer grew with it
+    assert b[8][7] and b[8][7] != 123 and b[18][7]             # the filter-gradient workspaces were sized by the adopting rank
