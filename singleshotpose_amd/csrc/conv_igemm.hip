@@ -580,6 +580,10 @@ int ssp_conv_igemm_launch(const float* in, const float* wt, float* out, const fl
     SSP_CHECK_ARG(bnb->nslot >= 1, "conv: the BatchNorm-backward partial buffer needs at least one row");
     a.bn_nslot = bnb->nslot;
   }
+  if (ssp_wino_plan_fused(plan)) {
+    a.ksplit = 1; a.ws = nullptr;
+    return ssp_wino_fused_launch(a, B, H, W, prof_kind, stream);
+  }
   if (ssp_wino_plan_tile(plan)) return wino_launch(a, B, H, W, ws, ws_floats, plan, prof_kind, stream);
   IgemmPlan pl = select_plan(a.M, Cin, Cout, R, plan);
   if (Cout <= 64 && pl.ksplit > 1 &&

@@ -198,6 +198,7 @@ int64_t ssp_conv_wino_tiles(int B, int H, int W, int tile) {
   return ssp_wino_tiles(B, H, W, tile);
 }
 int ssp_conv_stats_tiles(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  if (ssp_wino_plan_fused(plan)) return ssp_wino_fused_stat_groups(B, H, W, Cout);
   if (const int tile = ssp_wino_plan_tile(plan)) return (int)ssp_wino_stat_groups(B, H, W, tile);
   return ssp_cdiv((int64_t)B * H * W, ssp_conv_tile_m(B * H * W, Cin, Cout, R, plan));
 }
@@ -206,6 +207,7 @@ int64_t ssp_conv_stats_floats(int B, int H, int W, int Cin, int Cout, int R, int
   return nt * Cout * 2 + (ssp_wino_plan_tile(plan) ? nt : 0);
 }
 int64_t ssp_conv_workspace_floats(int B, int H, int W, int Cin, int Cout, int R, int plan) {
+  if (ssp_wino_plan_fused(plan)) return 0;      // V and M stay on the chip
   if (const int tile = ssp_wino_plan_tile(plan)) return ssp_wino_ws_floats(B, H, W, Cin, Cout, tile);      // V + M planes
   return ssp_conv_ws_floats(B * H * W, Cin, Cout, R, plan);
 }

@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 WINO = 9006413      # Winograd F(2x2), 64-row GEMM tiles, 3-slot ring
 WINO4 = 8006413     # Winograd F(4x4), same GEMM tiles
+FUSED = 7000001     # F(2x2) with the transform domain kept on the chip (csrc/conv_wino_fused.hip): one persistent launch
 
 
 def _tile(plan):
-    return 4 if plan < 9000000 else 2
+    from singleshotpose_amd import _lib
+    return _lib.query('ssp_conv_plan_wino_tile', plan)
 
 
 def _imports():
@@ -52,6 +54,16 @@ CASES = [
     (4, 21, 21, 128, 128, 16, True, WINO4),        # valid.py's grid: 121 tiles instead of 144; bias, sliced output
     (3, 9, 9, 32, 128, 0, False, WINO4),           # one mosaic, one phantom image
     (4, 13, 9, 64, 192, 0, False, WINO4),          # non-square
+    # on-chip F(2x2): a wave = a patch of 4 x 8 tiles x 32 output channels, workgroups walk (patch block, channel block) items
+    (2, 13, 13, 64, 128, 0, False, FUSED),         # odd map: half-empty tiles at the right / bottom edge, masked stores
+    (3, 14, 10, 128, 96, 32, True, FUSED),         # bias, sliced output, three channel blocks
+    (1, 21, 21, 256, 256, 0, False, FUSED),        # valid.py's grid; K loop of 8 stage pairs
+    (5, 7, 9, 32, 160, 0, False, FUSED),           # one stage pair (Cin = 32), tiny ragged patches
+    (64, 13, 13, 256, 512, 0, False, FUSED),       # benchmark grid: 4096 items, 16 per workgroup
+    (2, 1, 5, 64, 128, 0, False, FUSED),           # a single image row
+    (4, 104, 104, 64, 128, 0, False, FUSED),       # layer 4 / 6: 13 x 6.5 patches per image, several items per workgroup
+    (2, 208, 208, 32, 64, 0, False, FUSED),        # layer 2
+    (3, 24, 40, 64, 64, 0, False, FUSED),          # patches that tile the map exactly, fewer items than workgroups
 ]
 
 
@@ -110,7 +122,7 @@ def test_wino_conv_fwd(B, H, W, Cin, Cout, xout, bias, plan):
                                    (1 / torch.sqrt(r64.var(dim=(0, 2, 3), unbiased=False) + 1e-4)).numpy(), rtol=1e-4)
 
 
-@pytest.mark.parametrize("WINO", [WINO, WINO4])
+@pytest.mark.parametrize("WINO", [WINO, WINO4, FUSED])
 def test_wino_conv_fwd_affine_eval_block(WINO):
     """Inference form: BatchNorm affine + leaky applied by the finishing pass (ssp_conv_fwd_affine with a Winograd plan)."""
     G, _lib = _imports()
@@ -133,8 +145,9 @@ def test_wino_conv_fwd_affine_eval_block(WINO):
     assert rel_err(G.from_nhwc(out, B, Cout, H, W).numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("WINO", [WINO, WINO4])
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 128, 256), (3, 10, 14, 256, 128), (64, 13, 13, 128, 512), (7, 13, 9, 128, 128)])
+@pytest.mark.parametrize("WINO", [WINO, WINO4, FUSED])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 128, 256), (3, 10, 14, 256, 128), (64, 13, 13, 128, 512), (7, 13, 9, 128, 128),
+                                            (4, 104, 104, 64, 128)])
 def test_wino_conv_dgrad(B, H, W, Cin, Cout, WINO):
     """Data gradient with a Winograd plan: filters from the ssp_repack_dgrad layout; plain, accumulating, and with the
     BatchNorm-backward reductions of the producing block folded into the finishing pass (ssp_conv_dgrad_bnbwd)."""

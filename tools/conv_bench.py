@@ -122,7 +122,10 @@ def run_cases(args, dev, st, B):
         for plan in [int(v) for v in args.plans.split(',')]:
             tile = _lib.query('ssp_conv_plan_wino_tile', plan)      # 2 / 4: Winograd F(2x2) / F(4x4) plan, 0: direct
             wino = tile > 0
-            if wino and (R != 3 or Cin % 16 or Cout % 16 or Cout < 64 or Cin < 64):
+            fused = 7000000 <= plan < 8000000      # on-chip F(2x2) (csrc/conv_wino_fused.hip): 32-channel granularity both ways
+            if fused and (R != 3 or Cin % 32 or Cout % 32):
+                continue
+            if wino and not fused and (R != 3 or Cin % 16 or Cout % 16 or Cout < 64 or Cin < 64):
                 continue
             wsn = max(1, _lib.query('ssp_conv_workspace_floats', B, H, W, Cin, Cout, R, plan), _lib.query('ssp_conv_workspace_floats', B, H, W, coutp, Cin, R, plan))
             ws = torch.empty(wsn, device=dev)
