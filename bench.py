@@ -646,11 +646,12 @@ def main():
         # tiles = B * ceil(H/n) * ceil(W/n) - 16/36 resp. 36/144 of the direct multiplies, times the map's tile padding.
         # Every roofline object's `achieved` / `frac` is the EXECUTED rate (a fraction of the roofline it names, never > 1);
         # the algorithmic rate is reported next to it as `effective` (it can exceed the peak: fewer multiplies were needed).
-        from singleshotpose_amd.engine import wino_tile
+        from singleshotpose_amd.engine import wino_fused, wino_tile
         plan0 = next(iter(model._plans.values()))
         alg = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
         exe = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
         wino_layers = {f: {2: [], 4: []} for f in alg}
+        fused_layers = {f: [] for f in alg}      # ... of the F(2x2) layers, the ones that run the on-chip kernel (wino2_fused_kernel)
         for ind, cs in sorted(plan0.convs.items()):
             if cs.first:
                 continue
@@ -658,7 +659,16 @@ def main():
             for fam, n in (('fwd', wino_tile(cs.plan_fwd)), ('dgrad', wino_tile(cs.plan_dgrad)),
                            ('wgrad', int(getattr(cs, 'wgrad_wino', 0) or 0))):
                 alg[fam] += direct
-                if n:
+                code = {'fwd': cs.plan_fwd, 'dgrad': cs.plan_dgrad}.get(fam, 0)
+                if n and wino_fused(code):
+                    # on-chip F(2x2) (csrc/conv_wino_fused.hip): 16 planes x 128 tile slots per patch block (the launch's
+                    # statistics group) - partial patches at the map's edge multiply zeros like any tile padding
+                    ci, co = (cs.cinp, cs.cout) if fam == 'fwd' else (cs.coutp, cs.cin)
+                    tiles = 128 * _lib.query('ssp_conv_stats_tiles', B, cs.H, cs.W, ci, co, 3, code)
+                    exe[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    wino_layers[fam][2].append(ind)
+                    fused_layers[fam].append(ind)
+                elif n:
                     tiles = _lib.query('ssp_conv_wino_tiles', B, cs.H, cs.W, n)      # (the 2 x 2 image mosaic included)
                     exe[fam] += 2.0 * (n + 2) ** 2 * tiles * cs.cin * cs.cout
                     wino_layers[fam][n].append(ind)
@@ -690,7 +700,8 @@ def main():
                                   "flop_per_step": alg[fam],
                                   "note": "ALGORITHMIC (direct-convolution) FLOPs / the launch units' time: not a roofline "
                                           "fraction - Winograd layers need fewer multiplies than it counts"},
-                    "winograd_layers": {"F(2x2,3x3)": wino_layers[fam][2], "F(4x4,3x3)": wino_layers[fam][4]},
+                    "winograd_layers": {"F(2x2,3x3)": wino_layers[fam][2], "F(4x4,3x3)": wino_layers[fam][4],
+                                        "of F(2x2): on-chip (wino2_fused_kernel<FLAGS>: one persistent launch, no transform passes)": fused_layers[fam]},
                     "note": note}
 
         def hbm_family(fam, ms_, bytes_, n_):

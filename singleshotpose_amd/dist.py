@@ -9,7 +9,7 @@ Gradients of one backward live in ONE flat fp32 buffer laid out in reverse layer
 bucket is a contiguous slice: as soon as enough trailing layers have finished, its all-reduce is issued asynchronously
 (torch.distributed's RCCL stream orders itself after the work already queued on the compute stream) and overlaps the
 remaining wgrad/dgrad kernels.  xGMI is point-to-point: a ring all-reduce of the 202 MB gradient is bound by one
-~153 GB/s link (~2.3 ms) against a ~47 ms step, so a handful of large buckets is the right shape - with a SMALL last one,
+~153 GB/s link (~2.3 ms) against a ~27 ms step, so a handful of large buckets is the right shape - with a SMALL last one,
 because only the last bucket cannot overlap anything (GradReducer's tail rule).
 """
 import os
@@ -55,7 +55,9 @@ def sync_plans(model, group=None):
     (gradients agree after the all-reduce either way), and different step times, which in weak scaling show up as
     all-reduce wait on the faster ranks.  With this hook installed every plan, right after its own tuning (forward codes
     after the head-error budget; data- and filter-gradient codes after theirs), takes part in ONE broadcast of rank 0's
-    codes and adopts them.  The payload carries the plan's shape: a rank whose plan is of another shape keeps its own codes.
+    codes (a fixed-size message, so that ranks whose plans differ still pair up) and adopts them - all ranks together, or,
+    when any rank cannot (another plan shape, a code its environment switched off), all ranks fall back to the library's
+    deterministic heuristic plans for that stage.
     Requirement: all ranks build their plans in the same order (same sequence of input shapes) - bench.py and a training
     loop whose multi-scale schedule is seeded identically on every rank; a loop whose ranks draw shapes independently
     must not install it (the broadcasts would pair up wrongly)."""
@@ -63,11 +65,31 @@ def sync_plans(model, group=None):
         model._plan_sync = None
         return None
 
+    MAXN = 1023      # FIXED message size: ranks whose plans differ in shape / conv count still pair up (no size mismatch
+                     # inside the collective: NCCL would hang or corrupt before any guard could run)
+
     def fn(values):
+        """Broadcast rank 0's list (at most MAXN integers): returns rank 0's values, whatever this rank passed in."""
+        vals = [int(v) for v in values]
+        if len(vals) > MAXN:
+            raise ValueError("sync_plans: %d values exceed the fixed message size %d" % (len(vals), MAXN))
         dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
-        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        t = torch.zeros(MAXN + 1, dtype=torch.int64, device=dev)
+        t[0] = len(vals)
+        if vals:
+            t[1:1 + len(vals)] = torch.tensor(vals, dtype=torch.int64, device=dev)
         dist.broadcast(t, src=0, group=group)
-        return [int(v) for v in t.tolist()]
+        got = [int(v) for v in t.tolist()]
+        n = max(0, min(got[0], MAXN))
+        return got[1:1 + n]
+
+    def all_ok(flag):
+        """True only when EVERY rank passed a true flag (one MIN all-reduce): ranks adopt rank 0's codes all together, or none."""
+        dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+    fn.all_ok = all_ok
     model._plan_sync = fn
     return fn
 

@@ -23,6 +23,8 @@ from .cfg import layer_shapes, resolve_layers
 
 WINO = 9000000       # plan codes WINO + tile_rows*100 + 10 + ring_slots: Winograd F(2x2, 3x3) evaluation (csrc/conv_wino.hip)
 WINO4 = 8000000      # ... and WINO4 + the same: F(4x4, 3x3)
+WINOF = 7000001      # F(2x2, 3x3) with the transform domain kept on the chip (csrc/conv_wino_fused.hip): one persistent launch,
+                     # no workspace; same transformed filters, same arithmetic (and error family) as a WINO plan
 
 
 def _tune_tag():
@@ -31,13 +33,19 @@ def _tune_tag():
     from ever being timed - and must not hand a Winograd code to a process that switched it off."""
     if os.environ.get('SSP_WINOGRAD', '1') == '0':
         return 'r5-direct'
-    return 'r5-w%s-c%s-%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'),
-                              os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'))
+    return 'r6-w%s-c%s-%s-f%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'),
+                                  os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'), os.environ.get('SSP_WINO_FUSED', '1'))
+
+
+def wino_fused(code):
+    """True for the on-chip F(2x2) plan codes (7xxxxxx)."""
+    return 7000000 <= code < 8000000
 
 
 def wino_tile(code):
-    """Output-tile edge of a plan code: 2 / 4 for a Winograd plan, 0 for a direct one (ssp_conv_plan_wino_tile)."""
-    return 2 if WINO <= code < WINO + 1000000 else (4 if WINO4 <= code < WINO4 + 1000000 else 0)
+    """Output-tile edge of a plan code: 2 / 4 for a Winograd plan, 0 for a direct one (ssp_conv_plan_wino_tile).  The on-chip
+    F(2x2) codes count as tile 2: same filter transform, same error family."""
+    return 2 if (WINO <= code < WINO + 1000000 or wino_fused(code)) else (4 if WINO4 <= code < WINO4 + 1000000 else 0)
 BN_EPS = 1e-4        # darknet.py:157
 BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
 
@@ -453,13 +461,20 @@ class Plan(object):
         cand = [cs for cs in self.convs.values() if wino_tile(cs.plan_fwd) and 0 in (getattr(cs, 'fwd_fams', None) or {})]
         if not cand:
             return
+        # the NETWORK is part of the key: the deviations are properties of this stack of layers (another cfg at the same input
+        # shape - tiny-pose against yolo-pose, the multi-object cfg - must not run under this one's budget decisions)
+        import zlib
+        net_fp = zlib.crc32(repr([(i, cs.cin, cs.cout, cs.k, cs.H, cs.W, bool(cs.bn), bool(cs.pool))
+                                  for i, cs in sorted(self.convs.items())]).encode())
         ckey = (self.B, self.H, self.W, _tune_tag(), budget, id(self.net))
-        pkey = (self.B, self.H, self.W, _tune_tag(), budget)
+        pkey = (self.B, self.H, self.W, _tune_tag(), budget, net_fp)
         rec = _HEAD_BUDGET_CACHE.get(ckey)
         pinned = _HEAD_BUDGET_PINNED.get(pkey)
         if rec is None and pinned is not None and _TUNE_CACHE_FILE[0] and all(
                 any(c == pinned.get(cs.ind) for c, _ in cs.fwd_fams.values()) for cs in cand):
-            rec = dict(budget=budget, head_deviation=float('nan'), fastest={cs.ind: cs.plan_fwd for cs in cand}, chosen=dict(pinned),
+            # (entry -1 of a pinned record: the measured deviation of the chosen plans, in units of 1e-12)
+            rec = dict(budget=budget, head_deviation=pinned.get(-1, 0) * 1e-12 if -1 in pinned else float('nan'),
+                       fastest={cs.ind: cs.plan_fwd for cs in cand}, chosen={i: c for i, c in pinned.items() if i >= 0},
                        cost_ms=float('nan'), moved=[(cs.ind, wino_tile(cs.plan_fwd), wino_tile(pinned[cs.ind])) for cs in cand
                                                     if pinned[cs.ind] != cs.plan_fwd], table={}, pinned=True)
             _HEAD_BUDGET_CACHE[ckey] = rec
@@ -493,7 +508,9 @@ class Plan(object):
                         assign[cs.ind] = c_
                         d = float((run(assign) - ref).abs().max()) / den
                         rows.append((f_, c_, t_, d))
-                    rows.sort(key=lambda r: (r[2] if r[2] is not None else 0.0))
+                    # fastest first; the code the tuner actually chose (near-tie rule) leads among equals, so that `moved`
+                    # and `cost_ms` describe moves the layer really makes
+                    rows.sort(key=lambda r: (0 if r[1] == fastest[cs.ind] else 1, r[2] if r[2] is not None else 0.0))
                     table[cs.ind] = rows
             finally:
                 self.bn_momentum = mom
@@ -507,6 +524,7 @@ class Plan(object):
             _HEAD_BUDGET_CACHE[ckey] = rec
             if _TUNE_CACHE_FILE[0]:
                 _HEAD_BUDGET_PINNED[pkey] = dict(rec['chosen'])
+                _HEAD_BUDGET_PINNED[pkey][-1] = int(round(rec['head_deviation'] * 1e12))
                 _tune_cache_save()
         for cs in cand:
             cs.plan_fwd = rec['chosen'].get(cs.ind, cs.plan_fwd)
@@ -529,9 +547,24 @@ class Plan(object):
             mine = [self.convs[i].plan_dgrad for i in order] + [getattr(self.convs[i], 'wgrad_wino', 0) for i in order]
         head = [self.B, self.H, self.W, stage, len(order)]
         got = fn(head + mine)
-        if got[:5] != head or len(got) != len(head) + len(mine):
-            return                       # rank 0's plan is of another shape: keep this rank's own choices
-        vals = got[5:]
+        # Adopt only when EVERY rank can: same plan shape everywhere, and every code one this rank's environment allows
+        # (SSP_WINOGRAD / SSP_WINO_TILES / SSP_WINO_FUSED may differ between ranks' launch scripts).  Otherwise all ranks
+        # fall back to the library's heuristic plans (code 0) for this stage - deterministic and the same everywhere.
+        ok = got[:5] == head and len(got) == len(head) + len(mine)
+        if ok:
+            wino_on = os.environ.get('SSP_WINOGRAD', '1') != '0'
+            tiles = tuple(int(t) for t in os.environ.get('SSP_WINO_TILES', '2,4').split(',') if t)
+            fused_on = os.environ.get('SSP_WINO_FUSED', '1') != '0'
+            for k, v in enumerate(got[5:]):
+                if v == mine[k] or v == 0:
+                    continue
+                t = v if (stage == 1 and k >= len(order)) else wino_tile(v)      # (the filter gradients' entries ARE tile sizes)
+                if t and (not wino_on or t not in tiles or (wino_fused(v) and not fused_on)):
+                    ok = False
+        all_ok = getattr(fn, 'all_ok', None)
+        if all_ok is not None:
+            ok = all_ok(ok)
+        vals = got[5:] if ok else [0] * len(mine)
         for k, i in enumerate(order):
             cs = self.convs[i]
             if stage == 0:
@@ -621,7 +654,7 @@ class Plan(object):
         input is transformed once per step (csrc/conv_wgrad.hip ssp_conv_wgrad_wino_launch, x == NULL)."""
         if getattr(cs, 'wino_ws', None) is None:
             n = cs.wino_ws_floats
-            if wino_tile(cs.plan_fwd):
+            if wino_tile(cs.plan_fwd) and not wino_fused(cs.plan_fwd):
                 n = max(n, _lib.query('ssp_conv_workspace_floats', self.B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.plan_fwd))
             cs.wino_ws = torch.empty(n, dtype=torch.float32, device=self.device)
         return cs.wino_ws
@@ -696,7 +729,8 @@ class Plan(object):
                     cs.cin % 16 == 0 and cs.cout % 16 == 0 and cmin >= 64):
                 continue
             # tile sizes worth timing: F(2x2) from SSP_WINO_MIN_CHANNELS (128) channels on both sides, F(4x4) from 64
-            ts_ok = [t for t in tiles if cmin >= (int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128')) if t == 2 else 64) and
+            ts_ok = [t for t in tiles if cmin >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128') if t == 2 else
+                                                     os.environ.get('SSP_WINO4_MIN_CHANNELS', '64')) and
                      self.B * ((cs.H + t - 1) // t) * ((cs.W + t - 1) // t) >= 16]
             if not ts_ok:
                 continue
@@ -876,12 +910,22 @@ class Plan(object):
                 bases.append(WINO4)
             return tuple(bases)
 
+        fused_on = wino_on and os.environ.get('SSP_WINO_FUSED', '1') != '0' and 2 in wino_tiles
+
+        def fused_ok(cs, which):
+            """The on-chip F(2x2) kernel (csrc/conv_wino_fused.hip) fits: 3x3, channel counts multiples of 32 on both sides of
+            the launch (forward: Cin -> Cout; data gradient: Cout -> Cin), no channel padding."""
+            return (fused_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
+                    cs.cin % 32 == 0 and cs.cout % 32 == 0 and B * cs.H * cs.W * max(cs.inp.ld, cs.ldraw) * 4 < (1 << 31))
+
         def wino_codes(cs, which, small=False):
             codes = []
             for base in wino_bases(cs, which):
                 codes += [base + c for c in gemm_cands]
                 if small:      # small grids - batch-1 inference: also the 8-slot latency ring, as for the direct plans
                     codes += [base + 6418, base + 12818]
+            if fused_ok(cs, which):
+                codes.append(WINOF)
             return tuple(codes)
         def ws_need(cs):       # split-K scratch of the deepest candidate tried on this shape (x9 small, x4 mid, none big)
             mc = cs.M * max(cs.coutp, cs.cinp)
@@ -986,7 +1030,7 @@ class Plan(object):
             return 0
 
         for cs in elig:
-            if which == 'fwd' and cs.cout > 64:
+            if which == 'fwd' and (cs.cout > 64 or fused_ok(cs, which)):
                 # operand contents are irrelevant for timing: a channels-last-sized parameter stands in for itself
                 wop = cs.conv.weight if cs.cinp == cs.cin else self._wbuf(cs)
                 key = ('fwd', B, cs.H, cs.W, cs.cinp, cs.cout, cs.k, cs.inp.ld, cs.ldraw, bool(cs.bn), _tune_tag())
@@ -1018,7 +1062,8 @@ class Plan(object):
                 if wc and key not in _TUNE_CACHE:
                     for t in sorted(set(wino_tile(c) for c in wc)):
                         prep_f(t)
-                code = best_of(launch, cs.M * cs.coutp, key, wc)
+                # (Cout <= 64 ignores direct plan codes - its heuristic plan alone is timed against the Winograd forms)
+                code = best_of(launch, cs.M * cs.coutp, key, wc, direct=None if cs.cout > 64 else (0,))
                 a = cs.inp
                 ops_ = [(a.t, a.ld, a.off % a.ld, cs.cinp)] + ([] if wop is cs.conv.weight else [wop])
                 cs.plan_fwd = admitted(code, key, launch, lambda cs=cs: cs.raw, ops_, bn_of if cs.bn else None,
@@ -1033,6 +1078,11 @@ class Plan(object):
                                                  (lambda c_=c_: prep_f(wino_tile(c_))) if wino_tile(c_) else None,
                                                  primary=False) == c_:
                         cs.fwd_fams[f_] = (c_, t_)
+                # a direct family whose tuned code was refused still has the library's heuristic plan (code 0, the reference of
+                # every verification): the error budget must always be able to fall back to a direct launch
+                fams_ = _TUNE_FAMILY.get(key) or {}
+                if 0 not in cs.fwd_fams and 0 in fams_:
+                    cs.fwd_fams[0] = (0, fams_[0][1])
                 # not chosen: the transformed-filter buffers go back to the allocator
                 cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
             if which == 'dgrad' and not cs.first and cs.coutp % 16 == 0 and (cs.cin > 64 or wino_codes(cs, which)):
@@ -1238,7 +1288,8 @@ class Plan(object):
                 ws_t = self.ws
                 cs.v_live = False
                 share_v = os.environ.get('SSP_WINO_SHARE_V', '1') != '0'
-                if need_grad and wino_tile(cs.plan_fwd) and getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and share_v:
+                if (need_grad and wino_tile(cs.plan_fwd) and not wino_fused(cs.plan_fwd) and
+                        getattr(cs, 'wgrad_wino', 0) == wino_tile(cs.plan_fwd) and share_v):
                     ws_t = self._wino_ws(cs)         # V stays at the head of this buffer for the layer's filter gradient
                     cs.v_live = True
                 elif (need_grad and getattr(cs, 'wgrad_wino', 0) and share_v and self.side_stream is not None and
