@@ -660,7 +660,13 @@ def main():
                            ('wgrad', int(getattr(cs, 'wgrad_wino', 0) or 0))):
                 alg[fam] += direct
                 code = {'fwd': cs.plan_fwd, 'dgrad': cs.plan_dgrad}.get(fam, 0)
-                if n and wino_fused(code):
+                if fam == 'wgrad' and n == 12:
+                    # on-chip F(2x2) filter gradient (csrc/conv_wino_wgrad_fused.hip): 16 planes, two tiles per k-step
+                    tiles = B * ((cs.H + 1) // 2) * 2 * (((cs.W + 1) // 2 + 1) // 2)
+                    exe[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    wino_layers[fam][2].append(ind)
+                    fused_layers[fam].append(ind)
+                elif n and wino_fused(code):
                     # on-chip F(2x2) (csrc/conv_wino_fused.hip): 16 planes x 128 tile slots per patch block (the launch's
                     # statistics group) - partial patches at the map's edge multiply zeros like any tile padding
                     ci, co = (cs.cinp, cs.cout) if fam == 'fwd' else (cs.coutp, cs.cin)

@@ -402,12 +402,15 @@ int ssp_conv_wgrad_launch(const float* dy, const float* x, float* dw, int B, int
 // buffer transforms the layer input once per step.  dU needs no clearing by the caller: an un-split batched launch writes
 // it with plain stores, a split one zeroes it first.
 int64_t ssp_conv_wgrad_wino_ws_floats(int B, int H, int W, int Cin, int Cout, int tile) {
+  if (tile == SSP_WINO_WGRAD_FUSED) return ssp_wino_wgrad_fused_ws_floats(Cin, Cout);      // dU alone: V and dM stay on the chip
+  if (tile != 2 && tile != 4) return 0;
   const int64_t T = ssp_wino_tiles(B, H, W, tile);
   return ssp_wino_planes(tile) * (T * ((int64_t)Cin + Cout) + (int64_t)Cin * Cout);
 }
 int ssp_conv_wgrad_wino_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
                                int ldx, int tile, float* ws, int64_t ws_floats, hipStream_t stream) {
-  SSP_CHECK_ARG(tile == 2 || tile == 4, "wgrad (Winograd): tile must be 2 or 4");
+  if (tile == SSP_WINO_WGRAD_FUSED) return ssp_wino_wgrad_fused_launch(dy, x, dw, B, H, W, Cin, Cout, lddy, ldx, ws, ws_floats, stream);
+  SSP_CHECK_ARG(tile == 2 || tile == 4, "wgrad (Winograd): tile must be 2, 4 or 12 (F(2x2) with both transforms on the chip)");
   SSP_CHECK_ARG(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 64 && Cout >= 64, "wgrad (Winograd): needs Cin, Cout >= 64 and %% 16 == 0");
   SSP_CHECK_ARG(ldx % 4 == 0 && ldx >= Cin && lddy % 4 == 0 && lddy >= Cout, "wgrad (Winograd): bad leading dimensions");
   SSP_CHECK_ARG((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)ws)) % 16 == 0, "wgrad (Winograd): operands must be 16-byte aligned");

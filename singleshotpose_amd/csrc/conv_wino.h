@@ -52,3 +52,11 @@ struct ConvArgs;
 int ssp_wino_fused_launch(const ConvArgs& a, int B, int H, int W, int prof_kind, hipStream_t stream);
 int ssp_wino_fused_stat_groups(int B, int H, int W, int Cout);
 bool ssp_wino_fused_fits(int B, int H, int W, int Cin, int Cout, int R);
+
+// filter gradient with both Winograd transforms on the chip (conv_wino_wgrad_fused.hip): the `tile` value of
+// ssp_conv_wgrad_wino_t / ssp_conv_wgrad_wino_workspace_floats_t that selects it
+#define SSP_WINO_WGRAD_FUSED 12
+int ssp_wino_wgrad_fused_launch(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int lddy,
+                                int ldx, float* ws, int64_t ws_floats, hipStream_t stream);
+int64_t ssp_wino_wgrad_fused_ws_floats(int Cin, int Cout);
+bool ssp_wino_wgrad_fused_fits(int B, int H, int W, int Cin, int Cout);

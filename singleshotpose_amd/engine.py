@@ -23,6 +23,7 @@ from .cfg import layer_shapes, resolve_layers
 
 WINO = 9000000       # plan codes WINO + tile_rows*100 + 10 + ring_slots: Winograd F(2x2, 3x3) evaluation (csrc/conv_wino.hip)
 WINO4 = 8000000      # ... and WINO4 + the same: F(4x4, 3x3)
+WGRAD_FUSED = 12     # `tile` value of ssp_conv_wgrad_wino_t: F(2x2) filter gradient with both transforms on the chip
 WINOF = 7000001      # F(2x2, 3x3) with the transform domain kept on the chip (csrc/conv_wino_fused.hip): one persistent launch,
                      # no workspace; same transformed filters, same arithmetic (and error family) as a WINO plan
 
@@ -558,8 +559,9 @@ class Plan(object):
             for k, v in enumerate(got[5:]):
                 if v == mine[k] or v == 0:
                     continue
-                t = v if (stage == 1 and k >= len(order)) else wino_tile(v)      # (the filter gradients' entries ARE tile sizes)
-                if t and (not wino_on or t not in tiles or (wino_fused(v) and not fused_on)):
+                wg = stage == 1 and k >= len(order)                 # (the filter gradients' entries ARE tile sizes)
+                t = (2 if v == WGRAD_FUSED else v) if wg else wino_tile(v)
+                if t and (not wino_on or t not in tiles or ((v == WGRAD_FUSED if wg else wino_fused(v)) and not fused_on)):
                     ok = False
         all_ok = getattr(fn, 'all_ok', None)
         if all_ok is not None:
@@ -726,12 +728,16 @@ class Plan(object):
             cs.wgrad_wino = 0
             cmin = min(cs.cin, cs.cout)
             if not (wino_on and cs.k == 3 and not cs.first and cs.cinp == cs.cin and cs.coutp == cs.cout and
-                    cs.cin % 16 == 0 and cs.cout % 16 == 0 and cmin >= 64):
+                    cs.cin % 16 == 0 and cs.cout % 16 == 0):
                 continue
-            # tile sizes worth timing: F(2x2) from SSP_WINO_MIN_CHANNELS (128) channels on both sides, F(4x4) from 64
-            ts_ok = [t for t in tiles if cmin >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128') if t == 2 else
-                                                     os.environ.get('SSP_WINO4_MIN_CHANNELS', '64')) and
+            # tile sizes worth timing: F(2x2) from SSP_WINO_MIN_CHANNELS (128) channels on both sides, F(4x4) from 64 ...
+            ts_ok = [t for t in tiles if cmin >= 64 and cmin >= int(os.environ.get('SSP_WINO_MIN_CHANNELS', '128') if t == 2 else
+                                                                    os.environ.get('SSP_WINO4_MIN_CHANNELS', '64')) and
                      self.B * ((cs.H + t - 1) // t) * ((cs.W + t - 1) // t) >= 16]
+            # ... and F(2x2) with both transforms on the chip (WGRAD_FUSED: csrc/conv_wino_wgrad_fused.hip), 32-channel granularity
+            if (2 in tiles and os.environ.get('SSP_WINO_FUSED', '1') != '0' and cs.cin % 32 == 0 and cs.cout % 32 == 0 and
+                    (self.B * cs.H * cs.W + cs.W + 1) * max(cs.inp.ld, cs.ldraw) * 4 < (1 << 31)):
+                ts_ok.append(WGRAD_FUSED)
             if not ts_ok:
                 continue
             key = self._wgrad_key(cs)
@@ -780,6 +786,11 @@ class Plan(object):
                         break
                     try:
                         tt = timed(lambda out, t=t: wino(out, t))
+                        if t == WGRAD_FUSED:
+                            # timed alone, the HBM-bound transform passes of the other Winograd forms run at full bandwidth; in the
+                            # step they share it with the data-gradient stream.  SSP_WGRAD_FUSED_PREFER < 1 credits the on-chip
+                            # form (no such passes) with that difference (measured per shape: DESIGN.md section 3a)
+                            tt *= float(os.environ.get('SSP_WGRAD_FUSED_PREFER', '1.0'))
                         if not tt < 0.985 * t_best:
                             continue
                         # verification pair: one accumulation each into zeroed buffers

@@ -199,12 +199,16 @@ def test_wino_conv_dgrad(B, H, W, Cin, Cout, WINO):
     assert rel_err(got[:, 0].numpy(), s1.numpy()) < TOL and rel_err(got[:, 1].numpy(), s2.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 4, 12])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 13, 13, 128, 256), (3, 10, 14, 256, 64), (64, 13, 13, 256, 512), (16, 7, 9, 64, 192),
-                                            (64, 13, 13, 512, 1024), (7, 21, 13, 64, 128)])
+                                            (64, 13, 13, 512, 1024), (7, 21, 13, 64, 128), (4, 104, 104, 64, 128), (2, 208, 208, 32, 64),
+                                            (1, 5, 3, 32, 32)])
 def test_wino_conv_wgrad(B, H, W, Cin, Cout, tile):
     """Filter gradient in the Winograd domain (ssp_conv_wgrad_wino) against autograd of F.conv2d and against the direct
-    kernel; accumulates into dw (a second call doubles it)."""
+    kernel; accumulates into dw (a second call doubles it).  tile 12 = F(2x2) with both transforms on the chip
+    (csrc/conv_wino_wgrad_fused.hip: 32-channel granularity; the HBM forms need >= 64 channels)."""
+    if tile != 12 and (min(Cin, Cout) < 64 or B * ((H + tile - 1) // tile) * ((W + tile - 1) // tile) < 16):
+        pytest.skip("the HBM Winograd filter gradient needs >= 64 channels and >= 16 tiles")
     G, _lib = _imports()
     rs = np.random.RandomState(Cin * 5 + Cout + W)
     x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32))

@@ -145,13 +145,19 @@ def run_cases(args, dev, st, B):
                 # (the Winograd filter gradient of the tile size of THIS row's plan: direct rows skip it)
                 'wgradw': lambda: _lib.call('ssp_conv_wgrad_wino_t', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
                                             coutp, Cin, tile, wsw.data_ptr(), wsw.numel(), st),
+                # F(2x2) filter gradient with both transforms on the chip (csrc/conv_wino_wgrad_fused.hip)
+                'wgradf': lambda: _lib.call('ssp_conv_wgrad_wino_t', dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout,
+                                            coutp, Cin, 12, wsf.data_ptr(), wsf.numel(), st),
                 'wfilt': lambda: _lib.call('ssp_wino_filter_transform_t', w.data_ptr(), wf.data_ptr(), Cout, Cin, tile, st),
             }
             wsw = ws
+            wsf = torch.empty(max(16, 16 * Cin * Cout), device=dev)
             if 'wgradw' in args.ops.split(',') and wino and R == 3 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 64 and Cout >= 64:
                 wsw = torch.empty(_lib.query('ssp_conv_wgrad_wino_workspace_floats_t', B, H, W, Cin, Cout, tile), device=dev)
             line = '%-4s H=%3d Cin=%4d Cout=%4d R=%d plan %7d |' % (name, H, Cin, Cout, R, plan)
             for op in args.ops.split(','):
+                if op == 'wgradf' and (R != 3 or Cin % 32 or Cout % 32 or plan != int(args.plans.split(',')[0])):
+                    continue
                 if (op == 'dgrad' and name == 'l0') or (op == 'wfilt' and not wino) or (op == 'wgrad' and plan != int(args.plans.split(',')[0])) or (op == 'wgradw' and wsw is ws):
                     continue
                 fn = fns[op]
