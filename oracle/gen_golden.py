@@ -158,6 +158,20 @@ def gen_multiseed(ref_cfg=None, ref_darknet=None):
     for k in MULTISEED:
         run_net(ref_cfg, ref_darknet, os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 2, 416, 416, 7, True, 'full_train_s%d' % k,
                 input_seed=k, nslice=128)
+    gen_b8(ref_cfg, ref_darknet)
+
+
+B8_SEEDS = (221, 222)      # ... and two at the cfg's own batch (batch=8, yolo-pose.cfg:3): round-5 review, weak #2
+
+
+def gen_b8(ref_cfg=None, ref_darknet=None):
+    """darknet_full_train_b8_s<seed>.npz: the reference's float32 and float64 training step of cfg/yolo-pose.cfg on EIGHT images
+    (the same seeded weights, seed 7) - the un-frozen whole-network gradient statistic at the batch the cfg ships with."""
+    if ref_cfg is None:
+        _, ref_cfg, ref_darknet = import_reference()
+    for k in B8_SEEDS:
+        run_net(ref_cfg, ref_darknet, os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'), 8, 416, 416, 7, True, 'full_train_b8_s%d' % k,
+                input_seed=k, nslice=128)
 
 
 def main():
@@ -296,6 +310,8 @@ def gen_nms():
 if __name__ == '__main__':
     if 'multiseed' in sys.argv:
         gen_multiseed()
+    elif 'b8' in sys.argv:
+        gen_b8()
     elif '--eval' in sys.argv:
         gen_eval()
     elif '--nms' in sys.argv:

@@ -317,6 +317,7 @@ class Darknet(nn.Module):
         for plan in self._plans.values():
             plan.wversion.clear()
             plan.bnversion.clear()
+            plan.head_budget_stale()      # the rounding budget of the forward plans was measured on the OLD weights
 
     def load_weights(self, weightfile):
         self._load_blocks(self._read_weights(weightfile), len(self.blocks))

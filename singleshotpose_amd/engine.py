@@ -35,7 +35,8 @@ def _tune_tag():
     if os.environ.get('SSP_WINOGRAD', '1') == '0':
         return 'r5-direct'
     return 'r6-w%s-c%s-%s-f%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'),
-                                  os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'), os.environ.get('SSP_WINO_FUSED', '1'))
+                                  os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'),
+                                  os.environ.get('SSP_WINO_FUSED', '1') + os.environ.get('SSP_WGRAD_FUSED_PREFER', ''))
 
 
 def wino_fused(code):
@@ -384,6 +385,8 @@ class Plan(object):
         self.ws_floats = max([1] + [cs.ws_fwd for cs in self.convs.values()])
         self.ws = torch.empty(self.ws_floats, **f32)
         self._head_budget_done = False
+        self._hb_gains = None
+        self._hb_checked = 0
         self.head_budget = None      # record of Plan._apply_head_budget (what was measured, what was chosen)
         self.bn_momentum = BN_MOMENTUM
         self.wversion = {}
@@ -456,6 +459,8 @@ class Plan(object):
         3.5e-5 of the head's range; 0 = off: always the fastest code).  BatchNorm running statistics are not touched by the
         measurement forwards (momentum 0).  The record is kept in `plan.head_budget` (bench.py prints it)"""
         self._head_budget_done = True
+        self._hb_gains = None
+        self._hb_checked = self.generation
         budget = float(os.environ.get('SSP_HEAD_ERR_BUDGET', '3.5e-5'))
         if budget <= 0 or not self._tune:
             return
@@ -533,6 +538,46 @@ class Plan(object):
             cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
         self._fit_workspace()
         self.head_budget = rec
+        self._hb_gains = self._bn_gains()      # the amplification the decisions were measured under (head_budget_drifted)
+
+    # The deviations the budget admits a plan under are measured ONCE, on the weights and BatchNorm statistics of the plan's
+    # first training batch - and the amplification of a layer's rounding on the way to the head is a product of BatchNorm gains
+    # (|gamma| / sigma per block), which training moves.  Two triggers re-measure:
+    #   * load_weights / load_weights_until_last (Darknet._load_blocks): another network as far as rounding goes;
+    #   * every SSP_HEAD_BUDGET_EVERY (default 256) training forwards the largest |gamma * invstd| of every BatchNorm block is
+    #     compared with its value at measurement time (one stacked reduction, one 88-byte read): a block that moved by more
+    #     than 2x either way invalidates the record.  The re-measurement costs ~0.3 s (<= 27 forwards), like the first one.
+    def head_budget_stale(self):
+        if self._head_budget_done:
+            self._head_budget_done = False
+            for k in [k for k in _HEAD_BUDGET_CACHE if k[:3] == (self.B, self.H, self.W) and k[-1] == id(self.net)]:
+                _HEAD_BUDGET_CACHE.pop(k, None)
+            # (a pinned decision read from SSP_TUNE_CACHE belongs to the weights it was measured on, too)
+            for k in [k for k in _HEAD_BUDGET_PINNED if k[:3] == (self.B, self.H, self.W)]:
+                _HEAD_BUDGET_PINNED.pop(k, None)
+            # every timed family is a candidate again
+            for cs in self.convs.values():
+                fams = getattr(cs, 'fwd_fams', None)
+                if fams:
+                    best = min((v for v in fams.values() if v[1] is not None), key=lambda v: v[1], default=None)
+                    if best is not None and best[0] != cs.plan_fwd:
+                        cs.plan_fwd = best[0]
+                        self._size_layer(cs)
+            self._fit_workspace()
+
+    def _bn_gains(self):
+        bn = [cs for _, cs in sorted(self.convs.items()) if cs.bn]
+        if not bn:
+            return None
+        return torch.stack([cs.vec[2][:cs.cout].abs().max() for cs in bn]).cpu()
+
+    def head_budget_drifted(self):
+        """True when a BatchNorm block's largest |gamma * invstd| moved by more than 2x since the budget was measured."""
+        if self._hb_gains is None:
+            return False
+        now = self._bn_gains()
+        r = (now / self._hb_gains.clamp_min(1e-30)).clamp_min(1e-30)
+        return bool(((r > 2.0) | (r < 0.5)).any())
 
     def _sync_codes(self, stage):
         """Multi-GPU: adopt rank 0's plan codes (singleshotpose_amd.dist.sync_plans installs the hook on the model).
@@ -788,9 +833,10 @@ class Plan(object):
                         tt = timed(lambda out, t=t: wino(out, t))
                         if t == WGRAD_FUSED:
                             # timed alone, the HBM-bound transform passes of the other Winograd forms run at full bandwidth; in the
-                            # step they share it with the data-gradient stream.  SSP_WGRAD_FUSED_PREFER < 1 credits the on-chip
-                            # form (no such passes) with that difference (measured per shape: DESIGN.md section 3a)
-                            tt *= float(os.environ.get('SSP_WGRAD_FUSED_PREFER', '1.0'))
+                            # step they share it with the data-gradient stream.  SSP_WGRAD_FUSED_PREFER (default 0.8) credits the on-chip
+                            # form (no such passes) with that difference: same-box A/B of the whole step, two interleaved rounds, 26.64 / 26.45 ms
+                            # with 1.0 (layers 4 / 6 stay on the F(4x4) chain) against 26.12 / 26.13 ms with 0.8 (profiles/r06_step_ab.txt)
+                            tt *= float(os.environ.get('SSP_WGRAD_FUSED_PREFER', '0.8'))
                         if not tt < 0.985 * t_best:
                             continue
                         # verification pair: one accumulation each into zeroed buffers
@@ -1135,8 +1181,19 @@ class Plan(object):
             call('ssp_u8hwc_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, H, W, self.in_c, self.in_cp, self.in_cp, st)
         else:
             call('ssp_nchw_to_nhwc', x.data_ptr(), self.x_nhwc.data_ptr(), B, self.in_c, H, W, self.in_cp, self.in_cp, st)
+        if training and need_grad and self._head_budget_done and self._tune:
+            every = int(os.environ.get('SSP_HEAD_BUDGET_EVERY', '256'))
+            if every > 0 and self.generation - self._hb_checked >= every:
+                self._hb_checked = self.generation
+                drifted = self.head_budget_drifted()
+                sync = getattr(self.net, '_plan_sync', None)      # multi-GPU: BatchNorm statistics are per replica, the plan set
+                if sync is not None and hasattr(sync, 'all_ok'):  # is not - every rank re-measures when any rank drifted
+                    drifted = not sync.all_ok(not drifted)
+                if drifted:
+                    self.head_budget_stale()
         if training and need_grad and not self._head_budget_done:
-            self._apply_head_budget()        # once per plan, on its first training batch (network-level rounding budget)
+            self._apply_head_budget()        # on the plan's first training batch, after load_weights, and when the BatchNorm
+                                             # gains drifted (network-level rounding budget)
             self._sync_codes(0)              # multi-GPU: every rank runs rank 0's forward codes
         # (The whole training step as two captured hipGraphs was built and measured in round 4 - profiles/r04_step_graph.txt:
         # a replayed two-stream chain of ~300 nodes is SLOWER than launching it, 9.1 ms against 6.0 ms at batch 8 - and
