@@ -13,6 +13,11 @@
 // accumulator registers) and a CHUNK of tile rows; the launch is waves = blocks x chunks, and every wave ends with fp32
 // atomic adds of its 16 tiles into dU (zeroed in front of the launch).
 //
+// Measured (profiles/r06_pmc_conv.txt): the matrix pipe is busy 45 % of the launch - a wave is alone on its SIMD and the
+// compiler runs each k-step as three blocks (transforms, 16 MFMAs, 20 loads + scalar address work), so nothing overlaps the
+// MFMAs; dealing the loads between the MFMAs by hand (scheduling barriers) made the register allocator spill the
+// accumulators (15 ms).  Still 1.3 - 1.6 x faster than the direct kernel on the 208 x 208 / 104 x 104 layers.
+//
 // Loads run three k-steps (six tiles) ahead of the MFMAs in a ring of three register sets - the vmcnt counter allows 63
 // operations in flight, a k-step is 20.  Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the
 // per-row lane offsets, columns only on the first / last k-step of a row).

@@ -1292,6 +1292,8 @@ class Plan(object):
                 for cs, _ in wino:
                     wait_for[cs.ind] = ev
         if need_grad:
+            # (queueing these BEHIND the last on-chip Winograd forward launch - that kernel is persistent, one workgroup per CU,
+            # and shares the chip badly - was measured: 26.17 / 25.93 ms against 25.85 / 25.97 ms as is, nothing)
             for ind in sorted(self.convs.keys(), reverse=True):
                 cs = self.convs[ind]
                 if not cs.first:

@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        if not any(t in k for t in ('conv_', 'wino_', 'reduce_kernel')):
+        if not any(t in k for t in ('conv_', 'wino_', 'wino2_', 'reduce_kernel')):
             continue
         key = '%s grid=%s' % (k.replace('void ', '')[:48], r.get('Grid_Size', '?'))
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
