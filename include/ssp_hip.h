@@ -50,6 +50,13 @@ int ssp_set_option(const char* name, int value);
  *   ssp_wino_filter_transform_t with the plan's tile size (of the ssp_repack_fwd / ssp_repack_dgrad layout) and the
  *   workspace (ssp_conv_workspace_floats: (tile+2)^2 * tiles * (Cin + Cout) floats, tiles = ssp_conv_wino_tiles(B, H, W, tile))
  *   is mandatory; a Winograd code on a shape it does not fit is an error, not a fallback (the filter operand differs).
+ *   7000001 = Winograd F(2x2, 3x3) with the transform domain kept ON THE CHIP (conv_wino_fused.hip; ABI 5): ONE persistent
+ *   launch, no workspace (ssp_conv_workspace_floats = 0), `wt` = the same transformed filter as a 9xxxxxx plan
+ *   (ssp_wino_filter_transform_t, tile 2; ssp_conv_plan_wino_tile returns 2); Cin % 32 == 0 and Cout % 32 == 0 (no
+ *   lower bound of 64), 16-byte aligned in / out / bias / scale, ldin % 4 == 0, ldout % 4 == 0, every operand below
+ *   2 GiB; statistics in the counted format with one group per block of four 8 x 16-pixel patches
+ *   (ssp_conv_stats_tiles); accumulate, bias / affine and the fused BatchNorm-backward sums as for the other plans
+ *   (bias / affine may be combined with accumulate, the BatchNorm-backward sums with neither).
  *   Valid for ssp_conv_fwd, ssp_conv_fwd_affine, ssp_conv_dgrad and ssp_conv_dgrad_bnbwd.
  * stats of a Winograd plan are in the COUNTED format: ssp_conv_stats_tile_m returns 0, the buffer holds
  *   [ssp_conv_stats_tiles(...)][Cout][2] (mean, M2) pairs followed by [ssp_conv_stats_tiles(...)] pixel counts
@@ -114,7 +121,11 @@ int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int
  * workspace: ssp_conv_wgrad_wino_workspace_floats_t(...) floats.  x == NULL: the transformed input V is already at the head
  * of the workspace - left there by this layer's ssp_conv_fwd with a Winograd plan of the SAME tile size and the SAME
  * workspace buffer (both layouts start with V [(tile+2)^2][tiles][Cin]) - so the layer input is transformed once per
- * training step, not twice.  The un-suffixed names = tile 2. */
+ * training step, not twice.  The un-suffixed names = tile 2.
+ * tile = 12 (ABI 5): F(2x2) with BOTH transforms on the chip (conv_wino_wgrad_fused.hip) - each lane loads the 2 x 2
+ * output-gradient pixels / the 4 x 4 input window of its (channel, tile) and transforms them in registers, waves own a
+ * 32 x 32 channel block of all 16 planes over a chunk of tile rows and flush with fp32 atomics; Cin % 32 == 0 and
+ * Cout % 32 == 0 (from 32 channels up), x must be given (no shared transformed input), workspace = 16 * Cin * Cout floats. */
 int64_t ssp_conv_wgrad_wino_workspace_floats_t(int B, int H, int W, int Cin, int Cout, int tile);
 /* The input transform alone: V[(tile+2)^2][tiles][C] = B^T d B of x [B*H*W][ldx] - for a layer whose FORWARD does not run in
  * the Winograd domain (or runs another tile size) while its filter gradient does: the engine queues it on the second stream

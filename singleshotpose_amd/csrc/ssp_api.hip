@@ -166,7 +166,7 @@ SspProfScope::~SspProfScope() {
 extern "C" {
 
 const char* ssp_last_error(void) { return g_err; }
-int ssp_abi_version(void) { return 4; }
+int ssp_abi_version(void) { return 5; }
 int ssp_set_option(const char* name, int value) {
   for (int i = 0; i < SSP_OPT_COUNT; ++i)
     if (name != nullptr && strcmp(name, g_option_names[i]) == 0) {

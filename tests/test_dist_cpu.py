@@ -302,3 +302,67 @@ def test_plan_sync_adopts_rank0_codes_and_resizes():
     assert b[8][3] == 0 and b[12][3] == 0                      # Winograd plans: the counted statistics format (tile_m 0)
     assert b[8][5] > res[1][1][8][2] and res[1][2] >= b[8][5]   # ... a workspace for V | M, and the shared buffer grew with it
     assert b[8][7] and b[8][7] != 123 and b[18][7]             # the filter-gradient workspaces were sized by the adopting rank
+
+
+def _worker_plan_sync_refused(rank, world, port, q):
+    """Rank 1 runs with SSP_WINOGRAD=0 (its launch script switched the Winograd plans off): it cannot adopt rank 0's Winograd
+    codes, so NO rank does - every rank falls back to the library's heuristic plans (code 0), identically."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if rank == 1:
+        os.environ['SSP_WINOGRAD'] = '0'
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import ROOT
+    from singleshotpose_amd import engine
+    from singleshotpose_amd.darknet import Darknet
+    from singleshotpose_amd.dist import init_distributed, sync_plans
+    import torch.distributed as dist
+    init_distributed('gloo')
+    model = Darknet(os.path.join(ROOT, 'cfg', 'yolo-pose.cfg'))
+    fn = sync_plans(model)
+    assert fn is not None and hasattr(fn, 'all_ok')
+    plan = engine.Plan(model, 4, 160, 160, torch.device('cpu'))
+    for cs in plan.convs.values():
+        cs.plan_dgrad, cs.wgrad_wino = 0, 0
+    if rank == 0:
+        plan.convs[8].plan_fwd = 8006413
+        plan.convs[4].plan_fwd = engine.WINOF
+        plan.convs[13].plan_fwd = 12813
+        plan.convs[8].plan_dgrad, plan.convs[8].wgrad_wino = engine.WINOF, engine.WGRAD_FUSED
+        for i in (4, 8, 13):
+            plan._size_layer(plan.convs[i])
+    else:
+        plan.convs[13].plan_fwd = 6414      # this rank's own (direct) choice is dropped as well: same plans everywhere
+        plan._size_layer(plan.convs[13])
+    plan._sync_codes(0)
+    plan._sync_codes(1)
+    # a message of another SHAPE (rank 1's plan is for another input size) must neither hang nor be adopted
+    other = engine.Plan(model, 4, 160 if rank == 0 else 192, 160, torch.device('cpu'))
+    for cs in other.convs.values():
+        cs.plan_dgrad, cs.wgrad_wino = 0, 0
+    if rank == 0:
+        other.convs[13].plan_fwd = 12813
+    other._sync_codes(0)
+    q.put((rank, {i: (cs.plan_fwd, cs.plan_dgrad, cs.wgrad_wino) for i, cs in plan.convs.items()},
+           {i: cs.plan_fwd for i, cs in other.convs.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plan_sync_is_all_or_none_and_survives_a_shape_mismatch():
+    """ADVICE (round 5): the broadcast has a fixed size, the adoption is agreed by a MIN all-reduce - a rank that cannot run rank
+    0's codes makes every rank fall back to plan 0; ranks whose plans differ in shape pair up without a size mismatch."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_plan_sync_refused, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (a, b) for r, a, b in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert all(v == (0, 0, 0) for v in res[r][0].values()), (r, res[r][0])
+        assert all(v == 0 for v in res[r][1].values()), (r, res[r][1])

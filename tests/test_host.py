@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libssp_hip.so does not export %s" % name
     # the ctypes table covers the whole header and nothing else
     assert sorted(_lib.exported_symbols()) == declared
-    assert _lib.query('ssp_abi_version') == 4
+    assert _lib.query('ssp_abi_version') == 5
     with pytest.raises(_lib.SspError, match="unknown option"):
         _lib.call('ssp_set_option', b'no_such_knob', 1)
 
@@ -476,3 +476,14 @@ def test_tune_cache_file_keeps_family_tables_and_budget_decisions(tmp_path, monk
             d.clear()
             d.update(v)
         engine._TUNE_CACHE_FILE[0] = saved[3]
+
+
+def test_plan_code_families():
+    """Plan-code helpers of the engine: the on-chip F(2x2) code is a Winograd plan of tile 2 (same filter transform, same
+    error family in the head budget) and is told apart by wino_fused."""
+    from singleshotpose_amd import engine
+    assert engine.wino_tile(0) == 0 and engine.wino_tile(12813) == 0 and engine.wino_tile(306413) == 0
+    assert engine.wino_tile(9006413) == 2 and engine.wino_tile(8012814) == 4
+    assert engine.wino_tile(engine.WINOF) == 2 and engine.wino_fused(engine.WINOF)
+    assert not engine.wino_fused(9006413) and not engine.wino_fused(8006413) and not engine.wino_fused(0)
+    assert engine.WGRAD_FUSED == 12
