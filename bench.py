@@ -562,8 +562,8 @@ def main():
     # timed launch adds two event packets to its stream: all ~240 launches of a step timed cost 0.9 ms, these 23 cost
     # <0.1 ms).  --timers all / none change that.
     # (bit 0 = the forward conv launch units, bit 9 = the Winograd transform / finishing launches inside them: the dominant
-    # kernel's own time is the difference)
-    _lib.call('ssp_prof_enable', {'conv': (1 << 0) | (1 << 9), 'all': -1, 'none': 0}[args.timers])
+    # kernel's own time is the difference; bit 12 = the on-chip Winograd forward launches, a family of their own)
+    _lib.call('ssp_prof_enable', {'conv': (1 << 0) | (1 << 9) | (1 << 12), 'all': -1, 'none': 0}[args.timers])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -597,7 +597,7 @@ def main():
         plan.serial_backward = True
     ex_step = [([0.0] * nk, [0.0] * nk, [0] * nk)] if args.profile_run else []
     for _ in range(0 if args.profile_run else 3):
-        _lib.call('ssp_prof_enable', (1 << 1) | (1 << 2) | (1 << 10) | (1 << 11))      # dgrad, wgrad + their Winograd passes
+        _lib.call('ssp_prof_enable', (1 << 1) | (1 << 2) | (1 << 10) | (1 << 11) | (1 << 13) | (1 << 14))      # dgrad, wgrad, their Winograd passes, the on-chip forms
         loss = step()
         barrier()
         _lib.call('ssp_prof_enable', 0)
@@ -605,7 +605,7 @@ def main():
     for plan in model._plans.values():
         plan.serial_backward = False
     ex = {k: (float(np.median([p[0][k] for p in ex_step])), float(np.median([p[1][k] for p in ex_step])),
-              float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2, 10, 11)}
+              float(np.median([p[2][k] for p in ex_step]))) for k in (1, 2, 10, 11, 13, 14)}
     if dist_on:
         # communication diagnostics (untimed): per-bucket all-reduce issue -> done times and the exposed tail of one step
         reducer.profile = True
@@ -635,8 +635,11 @@ def main():
         if ig_ms <= 0:      # --timers none: take the forward launches of the breakdown pass
             ig_ms, ig_flop, ig_n, ig_steps, ig_wino = bms[0], bwork[0], bcnt[0], nb, bms[9]
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        bwd_ms = max(bms[1], bms[2])   # the two streams run concurrently: wall time of the conv backward ~ the longer one
-        bwd_tf = (bwork[1] + bwork[2]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        # on-chip Winograd forward launches (kind 12): same source as the dominant kernel's
+        oc_fwd = (ms[12] / args.steps, cnt[12] / args.steps) if ms[0] > 0 else (bms[12] / nb, bcnt[12] / nb)
+        # the two streams run concurrently: wall time of the conv backward ~ the longer one (on-chip launches with their stream)
+        bwd_ms = max(bms[1] + bms[13], bms[2] + bms[14])
+        bwd_tf = (bwork[1] + bwork[2] + bwork[13] + bwork[14]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         traffic, traffic_src = forward_traffic_per_launch()
         images_per_s = global_batch * args.steps / dt
 
@@ -649,7 +652,9 @@ def main():
         from singleshotpose_amd.engine import wino_fused, wino_tile
         plan0 = next(iter(model._plans.values()))
         alg = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
-        exe = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+        exe = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}      # executed FLOPs of the implicit-GEMM / filter-gradient kernel launches
+        exe_oc = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}   # ... of the on-chip Winograd launches (families of their own)
+        alg_oc = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
         wino_layers = {f: {2: [], 4: []} for f in alg}
         fused_layers = {f: [] for f in alg}      # ... of the F(2x2) layers, the ones that run the on-chip kernel (wino2_fused_kernel)
         for ind, cs in sorted(plan0.convs.items()):
@@ -663,7 +668,8 @@ def main():
                 if fam == 'wgrad' and n == 12:
                     # on-chip F(2x2) filter gradient (csrc/conv_wino_wgrad_fused.hip): 16 planes, two tiles per k-step
                     tiles = B * ((cs.H + 1) // 2) * 2 * (((cs.W + 1) // 2 + 1) // 2)
-                    exe[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    exe_oc[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    alg_oc[fam] += direct
                     wino_layers[fam][2].append(ind)
                     fused_layers[fam].append(ind)
                 elif n and wino_fused(code):
@@ -671,7 +677,8 @@ def main():
                     # statistics group) - partial patches at the map's edge multiply zeros like any tile padding
                     ci, co = (cs.cinp, cs.cout) if fam == 'fwd' else (cs.coutp, cs.cin)
                     tiles = 128 * _lib.query('ssp_conv_stats_tiles', B, cs.H, cs.W, ci, co, 3, code)
-                    exe[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    exe_oc[fam] += 2.0 * 16 * tiles * cs.cin * cs.cout
+                    alg_oc[fam] += direct
                     wino_layers[fam][2].append(ind)
                     fused_layers[fam].append(ind)
                 elif n:
@@ -684,7 +691,7 @@ def main():
                  "workload: <64, 128, %d, 3|4, 2, 2> (batched Winograd GEMMs and mid-size grids), <128, 128, %d, 3, 2, 2>, "
                  "<128, 64, %d, 3, 2, 2> (Cout <= 64), <256, 32, %d, 4, 4, 1> (Cout <= 32)")
 
-        def family(fam, kernel, ms_, n_, note, wino_ms):
+        def family(fam, kernel, ms_, n_, note, wino_ms, oc_ms=0.0):
             """MFMA roofline object of one conv family.  The DOMINANT KERNEL is the implicit-GEMM / filter-gradient MFMA
             kernel itself: achieved = EXECUTED FLOPs / the HIP-event time of its launches (= the launch units' time minus the
             HBM-bound Winograd transform / finishing launches inside them, which have their own roofline object).  The same
@@ -692,7 +699,7 @@ def main():
             gemm_ms = ms_ - (wino_ms or 0.0)
             tf = exe[fam] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             utf = exe[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
-            eff = alg[fam] / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            eff = alg[fam] / ((ms_ + oc_ms) * 1e-3) / 1e12 if ms_ + oc_ms > 0 else 0.0      # every layer of the pass, on-chip launches included
             return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     "flop_per_step": exe[fam], "ms_per_step": round(gemm_ms, 3), "launches_per_step": n_,
@@ -724,7 +731,7 @@ def main():
               hbm_family('wgrad', *ex[11])]
         hb_ms = sum(h["ms_per_step"] for h in hb)
         hb_bytes = sum(h["bytes_per_step"] for h in hb)
-        step_exec = exe['fwd'] + exe['dgrad'] + exe['wgrad'] + 4 * 2.0 * B * H * W * 32 * 27
+        step_exec = sum(exe.values()) + sum(exe_oc.values()) + 4 * 2.0 * B * H * W * 32 * 27
         res = {
             "metric": "images/sec (fwd+bwd) yolo-pose 416x416 bs=64/GPU",
             "value": round(images_per_s, 2),
@@ -753,22 +760,41 @@ def main():
                                     "HIP events around exactly these launches INSIDE the timed region (they run alone on the "
                                     "GPU): one pair per launch unit and one per Winograd transform / finishing launch inside it; "
                                     "achieved / frac = EXECUTED MFMA FLOPs / the GEMM launches' own time",
-                                    ig_wino / max(ig_steps, 1)),
+                                    ig_wino / max(ig_steps, 1), oc_fwd[0]),
                              traffic=traffic, traffic_source=traffic_src),
             "roofline_dgrad": family("dgrad", IGEMM % (1, 1, 1, 1, 1) + " (+ conv_igemm_kernel<64, 128, 2, 2, 4, 0, 1> for the "
                                      "20-channel head)", ex[1][0], ex[1][2],
                                      "kernel-exclusive: untimed pass with the filter gradients on the same stream "
-                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues", ex[10][0]),
+                                     "(Plan.serial_backward); includes the fused BatchNorm-backward epilogues", ex[10][0], ex[13][0]),
             "roofline_wgrad": family("wgrad", "conv_wgrad_dma_kernel<BMO, BNI, NSLOT, FOLD, BVEC>(WgradArgs): <256, 128, 3, false, "
                                      "false>, <128, 128, 3, ...>, <128, 64, 4, ...>, <64, 128, 4, ...>, <64, 64, 4, true, false>",
                                      ex[2][0], ex[2][2], "kernel-exclusive: untimed pass with the filter gradients on the same "
                                      "stream (Plan.serial_backward); the first layer's filter gradient is first_block_kernel<3> "
-                                     "(kernel_ms_per_step.first_block_bwd)", ex[11][0]),
+                                     "(kernel_ms_per_step.first_block_bwd)", ex[11][0], ex[14][0]),
+            # the on-chip Winograd F(2x2) kernels (round 6): persistent launches that keep V and M in registers / LDS - their own
+            # families, so that `roofline` stays the implicit-GEMM kernel's launches and nothing else
+            "roofline_onchip": {
+                "bound": "mfma",
+                "kernel": "wino2_fused_kernel<FLAGS> (csrc/conv_wino_fused.hip: forward and data gradient), wino2_wgrad_fused_kernel "
+                          "(csrc/conv_wino_wgrad_fused.hip: filter gradient incl. its zero / finishing launches)",
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "by_pass": {f: {"layers": fused_layers[f], "ms_per_step": round(m_, 3), "launches_per_step": n_,
+                                "achieved": round(exe_oc[f] / (m_ * 1e-3) / 1e12 if m_ > 0 else 0.0, 2),
+                                "frac": round(exe_oc[f] / (m_ * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if m_ > 0 else 0.0, 4),
+                                "flop_per_step": exe_oc[f],
+                                "effective_tflops": round(alg_oc[f] / (m_ * 1e-3) / 1e12 if m_ > 0 else 0.0, 2)}
+                            for f, (m_, n_) in (('fwd', oc_fwd), ('dgrad', (ex[13][0], ex[13][2])), ('wgrad', (ex[14][0], ex[14][2])))},
+                "note": "achieved / frac = EXECUTED MFMA FLOPs (16 planes x 128 tile slots per patch block; 16/36 of the direct "
+                        "multiplies) / HIP-event time of the launches - forward inside the timed region, backward kernel-exclusive "
+                        "(Plan.serial_backward); effective_tflops = the layers' ALGORITHMIC FLOPs over the same time.  The input / "
+                        "output-gradient transforms run on the SIMD's vector lanes inside these kernels (the fp32 MFMA shares them), "
+                        "which is why the executed fraction is lower than the implicit-GEMM kernel's while the launches are faster "
+                        "than the direct and the through-HBM Winograd forms of the same layers"},
             "roofline_bwd": {"bound": "mfma", "kernel": "in the real step: conv dgrad launch units (main stream) overlapped with "
                                                         "conv_wgrad_dma_kernel launch units (second stream)",
-                             "achieved": round((exe['dgrad'] + exe['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 if bwd_ms > 0 else 0.0, 2),
+                             "achieved": round((exe['dgrad'] + exe['wgrad'] + exe_oc['dgrad'] + exe_oc['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 if bwd_ms > 0 else 0.0, 2),
                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round((exe['dgrad'] + exe['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                             "frac": round((exe['dgrad'] + exe['wgrad'] + exe_oc['dgrad'] + exe_oc['wgrad']) / (bwd_ms / nb * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
                                            if bwd_ms > 0 else 0.0, 4),
                              "effective": {"tflops": round(bwd_tf, 2), "frac_of_peak": round(bwd_tf / PEAK_FP32_MFMA_TFLOPS, 4)},
                              "note": "EXECUTED dgrad+wgrad FLOPs / max(sum of dgrad event times, sum of wgrad event times); "

@@ -89,7 +89,7 @@ _RET64 = ('ssp_conv_workspace_floats', 'ssp_conv_wgrad_wino_workspace_floats', '
           'ssp_conv_stats_floats', 'ssp_conv_wino_tiles', 'ssp_first_wgrad_workspace_floats')
 
 PROF_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act", "layout", "region", "optim", "first_block_fwd",
-              "first_block_bwd", "wino_fwd", "wino_dgrad", "wino_wgrad")
+              "first_block_bwd", "wino_fwd", "wino_dgrad", "wino_wgrad", "onchip_fwd", "onchip_dgrad", "onchip_wgrad")
 
 
 def csrc_digest():

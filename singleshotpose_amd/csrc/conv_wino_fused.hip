@@ -660,7 +660,8 @@ int ssp_wino_fused_launch(const ConvArgs& a, int B, int H, int W, int prof_kind,
                     (a.bn_partial != nullptr ? 4 : 0);
   SSP_CHECK_ARG(flags <= 4, "conv (on-chip Winograd plan): the fused BatchNorm-backward sums need a plain data-gradient launch");
   SSP_CHECK_ARG(a.stats == nullptr || (flags & 6) == 0, "conv (on-chip Winograd plan): statistics only from a non-accumulating launch");
-  SspProfScope prof(prof_kind, stream, 2.0 * (double)a.M * a.Cout * 9.0 * a.Cin);      // algorithmic (direct) FLOPs
+  SspProfScope prof(prof_kind == SSP_PROF_CONV_DGRAD ? SSP_PROF_ONCHIP_DGRAD : SSP_PROF_ONCHIP_FWD, stream,
+                    2.0 * (double)a.M * a.Cout * 9.0 * a.Cin);      // algorithmic (direct) FLOPs
   switch (flags) {
     case 1: return wf_launch<1>(p, stream);
     case 2: return wf_launch<2>(p, stream);

@@ -235,7 +235,7 @@ int ssp_wino_wgrad_fused_launch(const float* dy, const float* x, float* dw, int 
   nchunk = (p.nrows + p.rpc - 1) / p.rpc;
   p.nunits = nchunk * p.nblk;
   p.div_nblk = ssp_fastdiv((unsigned)p.nblk); p.div_nib = ssp_fastdiv((unsigned)p.nib); p.div_th = ssp_fastdiv((unsigned)p.th);
-  SspProfScope prof(SSP_PROF_CONV_WGRAD, stream, 2.0 * (double)B * H * W * Cout * 9.0 * Cin);      // algorithmic (direct) FLOPs
+  SspProfScope prof(SSP_PROF_ONCHIP_WGRAD, stream, 2.0 * (double)B * H * W * Cout * 9.0 * Cin);      // algorithmic (direct) FLOPs
   const size_t n16 = (size_t)ssp_wino_wgrad_fused_ws_floats(Cin, Cout) / 4;
   const unsigned zb = (unsigned)((n16 + 1023) / 1024 < 4096 ? (n16 + 1023) / 1024 : 4096);
   hipLaunchKernelGGL(wino_wgrad_fused_zero_kernel, dim3(zb), dim3(256), 0, stream, reinterpret_cast<float4*>(ws), n16);

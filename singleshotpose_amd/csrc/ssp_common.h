@@ -50,7 +50,12 @@ enum SspProfKind {
   SSP_PROF_WINO_FWD = 9,
   SSP_PROF_WINO_DGRAD = 10,
   SSP_PROF_WINO_WGRAD = 11,
-  SSP_PROF_NKINDS = 12
+  // on-chip Winograd launches (conv_wino_fused.hip, conv_wino_wgrad_fused.hip): families of their own, NOT nested in 0 - 2, so
+  // that the implicit-GEMM kernel's launches (the dominant kernel of the roofline reports) stay a clean set
+  SSP_PROF_ONCHIP_FWD = 12,
+  SSP_PROF_ONCHIP_DGRAD = 13,
+  SSP_PROF_ONCHIP_WGRAD = 14,
+  SSP_PROF_NKINDS = 15
 };
 
 struct SspProfScope {
