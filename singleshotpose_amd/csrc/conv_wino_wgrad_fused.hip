@@ -16,7 +16,11 @@
 // Measured (profiles/r06_pmc_conv.txt): the matrix pipe is busy 45 % of the launch - a wave is alone on its SIMD and the
 // compiler runs each k-step as three blocks (transforms, 16 MFMAs, 20 loads + scalar address work), so nothing overlaps the
 // MFMAs; dealing the loads between the MFMAs by hand (scheduling barriers) made the register allocator spill the
-// accumulators (15 ms).  Still 1.3 - 1.6 x faster than the direct kernel on the 208 x 208 / 104 x 104 layers.
+// accumulators (15 ms); splitting the 16 planes over TWO waves per SIMD (128 accumulator registers each, the other wave's
+// loads under this wave's MFMAs) was correct and 10 % SLOWER (777 / 755 us against 702 / 681 us on layers 2 / 4): both
+// halves load the same 20 values, and 40 dword loads per SIMD and k-step is what bounds it - the per-lane dword loads
+// (lane = channel) are the limit of this form, not the overlap.  Still 1.3 - 1.6 x faster than the direct kernel on the
+// 208 x 208 / 104 x 104 layers.
 //
 // Loads run three k-steps (six tiles) ahead of the MFMAs in a ring of three register sets - the vmcnt counter allows 63
 // operations in flight, a k-step is 20.  Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the
