@@ -23,7 +23,7 @@
 // 208 x 208 / 104 x 104 layers.
 //
 // Loads run three k-steps (six tiles) ahead of the MFMAs in a ring of three register sets - the vmcnt counter allows 63
-// operations in flight, a k-step is 20.  Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the
+// operations in flight, a k-step is 12 (20 at a row's first).  Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the
 // per-row lane offsets, columns only on the first / last k-step of a row).
 #include <utility>
 
@@ -74,8 +74,12 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (int64_t)(p.W + 1) * p.ldx), 0, (int)WG_OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)WG_OOB, 0x00020000);
   const int ldx4 = p.ldx * 4, ldy4 = p.lddy * 4;
-  const unsigned lane_x = (unsigned)((lh * 2 * p.ldx + c0 + li) * 4);      // tile 2 s + lh: two pixels further right
-  const unsigned lane_y = (unsigned)((lh * 2 * p.lddy + n0 + li) * 4);
+  // k-step s of a tile row multiplies tiles s (lanes lh = 0) and s + ksr (lanes lh = 1): a lane walks CONSECUTIVE tiles, whose
+  // windows share two of their four columns - only the two new columns are loaded (12 loads per k-step instead of 20: the
+  // per-lane dword loads are what bounds this kernel) and their row-transformed values are carried over in registers
+  const unsigned lane_x = (unsigned)((lh * 2 * p.ksr * p.ldx + c0 + li) * 4);
+  const unsigned lane_y = (unsigned)((lh * 2 * p.ksr * p.lddy + n0 + li) * 4);
+  const int tw = (p.W + 1) >> 1;
 
   f32x16 acc[16];
 #pragma unroll
@@ -98,18 +102,29 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) vy[pp] = (2 * ty + pp < p.H) ? lane_y : WG_OOB;
   };
-  float rd[3][4], rx[3][16];                // raw sets in flight: the 2 x 2 output-gradient pixels, the 4 x 4 input window
+  float rd[3][4], rx[3][16];                // raw sets in flight: the 2 x 2 output-gradient pixels, the window columns (all four at a
+                                            // row's first k-step, else the two new ones: j = 2, 3)
   auto issue = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
     if (lrow >= row1) return;
-    const bool edge = ls == 0 || ls == p.ksr - 1;      // the row's first / last tile pair: columns may fall outside the image
-    const int sx = l_sox + ls * 4 * ldx4, sy = l_soy + ls * 4 * ldy4;
-    if (edge) {
-      const int xcol = 4 * ls + 2 * lh;                // first output column of this lane's tile
+    // columns may fall outside the image at a row's first k-step (lanes lh = 0: column -1) and at its last ones (lanes lh = 1)
+    const bool edge = ls == 0 || ls + p.ksr >= tw - 1;
+    const int sx = l_sox + ls * 2 * ldx4, sy = l_soy + ls * 2 * ldy4;
+    const int xcol = 2 * (ls + lh * p.ksr);            // first output column of this lane's tile
+    if (ls == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
+          const unsigned v = ((unsigned)(xcol - 1 + j) < (unsigned)p.W) ? vx[i] : WG_OOB;
+          rx[K][i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, v, sx + (i * p.W + j) * ldx4, 0));
+        }
+    }
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 2; j < 4; ++j) {
           const unsigned v = ((unsigned)(xcol - 1 + j) < (unsigned)p.W) ? vx[i] : WG_OOB;
           rx[K][i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, v, sx + (i * p.W + j) * ldx4, 0));
         }
@@ -124,7 +139,7 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 2; j < 4; ++j)
           rx[K][i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vx[i], sx + (i * p.W + j) * ldx4, 0));
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
@@ -138,6 +153,8 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
     }
   };
   // ---- one k-step: transforms in registers, 16 MFMAs (A = dM: rows = output channels, B = V: columns = input channels) ----
+  int cs = 0;                               // k-step of the set being consumed (0 = a row's first: all four columns are fresh)
+  float tc[4][2];                           // row-transformed window columns 2, 3 of the previous k-step = columns 0, 1 of this one
   auto consume = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
     // dM = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
@@ -148,14 +165,26 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
     dm[4] = s0;   dm[5] = s0 + s1;    dm[6] = s0 - s1;    dm[7] = -s1;
     dm[8] = m0;   dm[9] = m0 + m1;    dm[10] = m0 - m1;   dm[11] = -m1;
     dm[12] = -d10; dm[13] = -d10 - d11; dm[14] = d11 - d10; dm[15] = d11;
-    // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: the row step per window column (columns 0, 1 carried over
+    // from the previous tile unless this is the row's first), then the column step
     float v[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    auto rowstep = [&](int j) {
       const float a0 = rx[K][j] - rx[K][8 + j], a1 = rx[K][4 + j] + rx[K][8 + j], a2 = rx[K][8 + j] - rx[K][4 + j],
                   a3 = rx[K][4 + j] - rx[K][12 + j];
       v[j] = a0; v[4 + j] = a1; v[8 + j] = a2; v[12 + j] = a3;
+    };
+    if (cs == 0) {
+      rowstep(0);
+      rowstep(1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[4 * i] = tc[i][0]; v[4 * i + 1] = tc[i][1]; }
     }
+    rowstep(2);
+    rowstep(3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { tc[i][0] = v[4 * i + 2]; tc[i][1] = v[4 * i + 3]; }
+    if (++cs == p.ksr) cs = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a0 = v[4 * i] - v[4 * i + 2], a1 = v[4 * i + 1] + v[4 * i + 2], a2 = v[4 * i + 2] - v[4 * i + 1],
@@ -169,6 +198,8 @@ __global__ void __launch_bounds__(256, 1) wino2_wgrad_fused_kernel(WinoWgradFuse
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
 
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { tc[i][0] = 0.f; tc[i][1] = 0.f; }
   const int nsteps = (row1 - row0) * p.ksr;
   set_row();
   issue(K0{});
