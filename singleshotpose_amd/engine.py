@@ -386,6 +386,7 @@ class Plan(object):
         self.ws = torch.empty(self.ws_floats, **f32)
         self._head_budget_done = False
         self._hb_gains = None
+        self._hb_gains_after_forward = False
         self._hb_checked = 0
         self.head_budget = None      # record of Plan._apply_head_budget (what was measured, what was chosen)
         self.bn_momentum = BN_MOMENTUM
@@ -460,6 +461,7 @@ class Plan(object):
         measurement forwards (momentum 0).  The record is kept in `plan.head_budget` (bench.py prints it)"""
         self._head_budget_done = True
         self._hb_gains = None
+        self._hb_gains_after_forward = False
         self._hb_checked = self.generation
         budget = float(os.environ.get('SSP_HEAD_ERR_BUDGET', '3.5e-5'))
         if budget <= 0 or not self._tune:
@@ -538,7 +540,10 @@ class Plan(object):
             cs.wino_u = {t: b for t, b in (getattr(cs, 'wino_u', None) or {}).items() if t == wino_tile(cs.plan_fwd)}
         self._fit_workspace()
         self.head_budget = rec
-        self._hb_gains = self._bn_gains()      # the amplification the decisions were measured under (head_budget_drifted)
+        # the amplification the decisions were measured under (head_budget_drifted).  A record adopted from the cache ran no
+        # measurement forward here: the scale vectors of this batch exist only after the forward body (forward() takes them)
+        self._hb_gains = None if rec.get('pinned') else self._bn_gains()
+        self._hb_gains_after_forward = bool(rec.get('pinned'))
 
     # The deviations the budget admits a plan under are measured ONCE, on the weights and BatchNorm statistics of the plan's
     # first training batch - and the amplification of a layer's rounding on the way to the head is a product of BatchNorm gains
@@ -1199,6 +1204,9 @@ class Plan(object):
         # a replayed two-stream chain of ~300 nodes is SLOWER than launching it, 9.1 ms against 6.0 ms at batch 8 - and
         # removed in round 5: it mirrored this method's host-side state by hand.  Inference keeps its graph, forward_graph.)
         self._forward_body(training, need_grad, inline_repack)
+        if training and getattr(self, '_hb_gains_after_forward', False):
+            self._hb_gains_after_forward = False
+            self._hb_gains = self._bn_gains()
         o = self.out_act
         y = torch.empty(B, o.C, o.H, o.W, dtype=torch.float32, device=self.device)
         call('ssp_nhwc_to_nchw', o.ptr, y.data_ptr(), B, o.C, o.H, o.W, o.ld, st)
