@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssp_hip.so")
+# (SSP_HIP_LIB: another build of the SAME library - e.g. the previous commit's kernels - for same-box A/B timing)
+LIB_PATH = os.environ.get("SSP_HIP_LIB") or os.path.join(_HERE, "libssp_hip.so")
 
 
 class SspError(RuntimeError):

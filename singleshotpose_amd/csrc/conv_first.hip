@@ -126,7 +126,7 @@ __device__ __forceinline__ void chan_combine_f(float& n, float& mean, float& m2,
 // MODE 0: forward statistics, 1: forward apply, 2: backward reduce, 3: backward filter gradient,
 // 4: write the raw convolution output (checkers only: the training path never stores it)
 template <int MODE>
-__global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
+__global__ void __launch_bounds__(256, 3) first_block_kernel(FirstArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,17 +167,47 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
   if (MODE == 1 || MODE == 4) rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)FIRST_OOB, 0x00020000);
   if (MODE >= 2) rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (int)FIRST_OOB, 0x00020000);
 
-  u32x2 xa[9], xn[9];
-  FirstBlock kb = first_decode(p, blk0 < p.nblocks ? blk0 : 0);
-  if (nblk > 0) first_load(p, rs_x, kb, lane_pix_off, lh, pp, q, xa);
-
-  for (int ib = 0; ib < nblk; ++ib) {
-    const FirstBlock k = kb;
-    const bool more = ib + 1 < nblk;
-    if (more) {                                          // next block's loads fly during this block's MFMAs
-      kb = first_decode(p, blk0 + ib + 1);
-      first_load(p, rs_x, kb, lane_pix_off, lh, pp, q, xn);
+  // Two register sets (input pairs of the 9 taps + the 4 pooled gradients of the backward modes), the loop unrolled by two:
+  // block n + 1's set is fetched - unconditionally: past the wave's last block the last one again, so that every path issues
+  // the same loads and the compiler's vmcnt bookkeeping stays exact - in front of block n's MFMAs.
+  auto fetch = [&](const FirstBlock& k, u32x2 (&xa)[9], float (&gv)[4]) {
+    first_load(p, rs_x, k, lane_pix_off, lh, pp, q, xa);
+    if constexpr (MODE == 2 || MODE == 3) {
+      const int pooled_u = __builtin_amdgcn_readfirstlane((k.b * p.Ho + k.yo) * p.Wo + 8 * k.xb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        gv[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, (unsigned)((4 * lh * p.ldg + cout) * 4),
+                                                                                (pooled_u + c) * p.ldg * 4, 0));
     }
+  };
+  auto compute = [&](const FirstBlock& k, const FirstBlock& kn, const u32x2 (&xa)[9], const float (&gv)[4], u32x2 (&xn)[9],
+                     float (&gn)[4]) {
+    // MODE 3: the 16 input-patch values of the filter-gradient MFMAs (B operand: lane = column j' = (tap, channel), step r =
+    // pixel pair) go first - they hit the lines this block's own taps just fetched and land under the 18 convolution MFMAs -
+    // then the next block's set (a fresh HBM stream, a whole block of work ahead of its use)
+    float bv[16];
+    if constexpr (MODE == 3) {
+      const int base_pix = __builtin_amdgcn_readfirstlane((k.b * p.H + 2 * k.yo) * p.W + 16 * k.xb);
+      if (!k.border) {
+        const unsigned voff = (li < 27) ? (unsigned)w_lane_off : FIRST_OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = r & 3, w = r >> 2;
+          bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              rs_xs, voff, (base_pix + (w >> 1) * p.W + (w & 1) + 2 * c) * 16, 0));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = r & 3, w = r >> 2;
+          const int y = 2 * k.yo + (w >> 1) + jt / 3 - 1, x = 16 * k.xb + 2 * (c + 4 * lh) + (w & 1) + jt % 3 - 1;
+          const bool ok = (li < 27) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+          const unsigned voff = ok ? (unsigned)((((k.b * p.H + y) * p.W + x) * 4 + jc) * 4) : FIRST_OOB;
+          bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff, 0, 0));
+        }
+      }
+    }
+    fetch(kn, xn, gn);
     const f32x16 acc = first_conv(xa, wreg);
     // pooled pixels of this block start at pooled_u (wave-uniform); the lane owns pixels 4*lh + {0,1,2,3}: the lane part
     // of an address sits in the (fixed) vector offset, the block / pixel part in the scalar offset
@@ -222,8 +252,7 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
       int sel[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-            rs_g, (unsigned)((4 * lh * p.ldg + cout) * 4), (pooled_u + c) * p.ldg * 4, 0));
+        const float gvc = gv[c];
         float y0 = acc[c] * sc + sh;
         float best = y0 > 0.f ? y0 : y0 * p.slope, ybest = y0, xbest = acc[c];
         int s = 0;
@@ -233,7 +262,7 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
           const float a = y > 0.f ? y : y * p.slope;
           if (a > best) { best = a; ybest = y; xbest = acc[c + 4 * w]; s = w; }
         }
-        dyv[c] = ybest > 0.f ? gv : gv * p.slope;
+        dyv[c] = ybest > 0.f ? gvc : gvc * p.slope;
         xh_sel[c] = (xbest - mu) * is;
         sel[c] = s;
       }
@@ -243,41 +272,38 @@ __global__ void __launch_bounds__(256) first_block_kernel(FirstArgs p) {
       } else {
         // dx of the 16 raw pixels, then dW[cout][j'] += sum_pixels dx[pixel][cout] * patch[pixel][j']:
         // MFMA step r takes pixel rows (r&3) + 8*(r>>2) (+4 for the upper lane half) - exactly where dx[r] already sits
-        const int base_pix = __builtin_amdgcn_readfirstlane((k.b * p.H + 2 * k.yo) * p.W + 16 * k.xb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = r & 3, w = r >> 2;
           const float xh = (acc[r] - mu) * is;
           const float dyq = (sel[c] == w) ? dyv[c] : 0.f;
           const float dx = sc * (dyq - k1 - xh * k2);
-          float bval;
-          if (!k.border) {
-            const unsigned voff = (li < 27) ? (unsigned)w_lane_off : FIRST_OOB;
-            bval = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                rs_xs, voff, (base_pix + (w >> 1) * p.W + (w & 1) + 2 * c) * 16, 0));
-          } else {
-            const int y = 2 * k.yo + (w >> 1) + jt / 3 - 1, x = 16 * k.xb + 2 * (c + 4 * lh) + (w & 1) + jt % 3 - 1;
-            const bool ok = (li < 27) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
-            const unsigned voff = ok ? (unsigned)((((k.b * p.H + y) * p.W + x) * 4 + jc) * 4) : FIRST_OOB;
-            bval = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff, 0, 0));
-          }
-          accw = __builtin_amdgcn_mfma_f32_32x32x2f32(dx, bval, accw, 0, 0, 0);
+          accw = __builtin_amdgcn_mfma_f32_32x32x2f32(dx, bv[r], accw, 0, 0, 0);
         }
       }
     }
-    if (more) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) xa[t] = xn[t];
+  };
+
+  u32x2 xa[9], xb[9];
+  float ga[4], gb[4];
+  const int last = blk0 + nblk - 1;
+  FirstBlock ka = first_decode(p, nblk > 0 ? blk0 : 0), kb = ka;
+  if (nblk > 0) fetch(ka, xa, ga);
+  for (int g0 = 0; g0 < nblk; g0 += 8) {                 // (groups of 8 blocks: the fold of MODE 3 sits OUTSIDE the block loop -
+    const int ge = min(nblk, g0 + 8);                    // inside, the compiler turned it into selects run on every block)
+    for (int ib = g0; ib < ge; ib += 2) {
+      kb = first_decode(p, min(blk0 + ib + 1, last));
+      compute(ka, kb, xa, ga, xb, gb);
+      ka = first_decode(p, min(blk0 + ib + 2, last));
+      if (ib + 1 < nblk) compute(kb, ka, xb, gb, xa, ga);
     }
     if constexpr (MODE == 3) {
-      if ((ib & 7) == 7) {
-        acct += accw;
+      acct += accw;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accw[r] = 0.f;
-      }
+      for (int r = 0; r < 16; ++r) accw[r] = 0.f;
     }
   }
-  if constexpr (MODE == 3) accw += acct;
+  if constexpr (MODE == 3) accw = acct;
 
   // ---- workgroup results ----
   __shared__ __attribute__((aligned(16))) float red[4][32][32];
