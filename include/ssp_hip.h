@@ -124,8 +124,9 @@ int ssp_conv_wgrad(const float* dy, const float* x, float* dw, int B, int H, int
  * training step, not twice.  The un-suffixed names = tile 2.
  * tile = 12 (ABI 5): F(2x2) with BOTH transforms on the chip (conv_wino_wgrad_fused.hip) - each lane loads the 2 x 2
  * output-gradient pixels / the 4 x 4 input window of its (channel, tile) and transforms them in registers, waves own a
- * 32 x 32 channel block of all 16 planes over a chunk of tile rows and flush with fp32 atomics; Cin % 32 == 0 and
- * Cout % 32 == 0 (from 32 channels up), x must be given (no shared transformed input), workspace = 16 * Cin * Cout floats. */
+ * 32 x 32 channel block of all 16 planes over a chunk of tile rows, back-transform their own sums (G^T dU G is linear) and
+ * add nine taps per channel pair into dw with fp32 atomics; Cin % 32 == 0 and Cout % 32 == 0 (from 32 channels up), x must
+ * be given (no shared transformed input), NO workspace (the query returns 0; a workspace argument is ignored). */
 int64_t ssp_conv_wgrad_wino_workspace_floats_t(int B, int H, int W, int Cin, int Cout, int tile);
 /* The input transform alone: V[(tile+2)^2][tiles][C] = B^T d B of x [B*H*W][ldx] - for a layer whose FORWARD does not run in
  * the Winograd domain (or runs another tile size) while its filter gradient does: the engine queues it on the second stream

@@ -2,29 +2,29 @@
 // (ssp_conv_wgrad_wino_t with tile = SSP_WINO_WGRAD_FUSED; the forward / data-gradient counterpart is conv_wino_fused.hip).
 //
 //   dU_xi [Cout][Cin] = sum over the tiles t of  dM_xi[t][Cout] (x) V_xi[t][Cin],   dM = A dY A^T,  V = B^T d B,  xi = 0 .. 15
-//   dw [Cout][3][3][Cin] += G^T dU G                                                  (wino_wgrad_finish_kernel<2>)
+//   dw [Cout][3][3][Cin] += G^T dU G                                                  (in the flush of every wave)
 //
 // conv_wino.hip runs this as four launches around 2 x 4 floats per pixel and channel of HBM traffic (V and dM written and
 // read): on the wide maps - 32 -> 64 channels at 208 x 208, 64 -> 128 at 104 x 104 - the transforms cost more than the GEMM.
-// Here the contraction index is the TILE: a lane of the A operand holds (output channel li, tile 2 s + lh), a lane of the B
-// operand (input channel li, tile 2 s + lh) - so a lane simply LOADS the 2 x 2 output-gradient pixels / the 4 x 4 input window
-// of its tile at its channel (32 lanes = 128 contiguous bytes per pixel), transforms them in registers, and the 16 results are
-// its operands of the 16 planes' MFMAs.  No LDS at all.  A wave owns a 32 x 32 (Cout x Cin) block of all 16 planes (256
-// accumulator registers) and a CHUNK of tile rows; the launch is waves = blocks x chunks, and every wave ends with fp32
-// atomic adds of its 16 tiles into dU (zeroed in front of the launch).
+// Here the contraction index is the TILE: a lane of the A operand holds (output channel li, tile u + lh ksr), a lane of the B
+// operand (input channel li, same tile) - so a lane simply LOADS the 2 x 2 output-gradient pixels / the new columns of the
+// 4 x 4 input window of its tile at its channel (32 lanes = 128 contiguous bytes per pixel), transforms them in registers, and
+// the 16 results are its operands of the 16 planes' MFMAs.  No LDS at all.  A wave owns a 32 x 32 (Cout x Cin) block of all
+// 16 planes (256 accumulator registers) and a CHUNK of tile rows; the launch is waves = blocks x chunks (one per SIMD), and
+// every wave ends by back-transforming its own sums (G^T dU G is linear) and adding nine taps per channel pair into dw.
 //
-// Measured (profiles/r06_pmc_conv.txt): the matrix pipe is busy 45 % of the launch - a wave is alone on its SIMD and the
-// compiler runs each k-step as three blocks (transforms, 16 MFMAs, 20 loads + scalar address work), so nothing overlaps the
-// MFMAs; dealing the loads between the MFMAs by hand (scheduling barriers) made the register allocator spill the
-// accumulators (15 ms); splitting the 16 planes over TWO waves per SIMD (128 accumulator registers each, the other wave's
-// loads under this wave's MFMAs) was correct and 10 % SLOWER (777 / 755 us against 702 / 681 us on layers 2 / 4): both
-// halves load the same 20 values, and 40 dword loads per SIMD and k-step is what bounds it - the per-lane dword loads
-// (lane = channel) are the limit of this form, not the overlap.  Still 1.3 - 1.6 x faster than the direct kernel on the
-// 208 x 208 / 104 x 104 layers.
+// What bounds it, measured (probes of this file under SSP_PROBES): of 605 us on layer 4, 350 are the
+// MFMAs (702 steps x 16 x 64 cycles at the ~2.05 GHz the chip sustains), ~100 the transforms / load issue / cursor (the fp32
+// MFMA runs on the vector lanes: VALU work adds to it instead of hiding under it), 29 the flush and ~45 were the zeroing and
+// finishing launches of the first version (dU in memory: gone).  Before the loads were taken out of the compiler's hands
+// (wg_load) the same loop was latency-bound: 680-700 us, 45 % MFMA-busy.
+// Tried and dropped: dealing the loads between the MFMAs by scheduling barriers (the allocator spilled the accumulators:
+// 15 ms); the 16 planes split over TWO waves per SIMD (correct, 10 % slower: both halves load the same values); ring depths
+// 4 and 5 (the same time as 3: with exact waits the loads are not the bound); a branch-free cursor (descriptor selects: the
+// compiler turned them into waterfall loops and moved the accumulators between iterations).
 //
-// Loads run three k-steps (six tiles) ahead of the MFMAs in a ring of three register sets - the vmcnt counter allows 63
-// operations in flight, a k-step is 12 (20 at a row's first).  Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the
-// per-row lane offsets, columns only on the first / last k-step of a row).
+// Zero padding and ragged edges: out-of-range buffer offsets (rows of the image in the per-row lane offsets, columns on the
+// primer / last steps of a row).
 #include <utility>
 
 #include "conv_wino.h"
