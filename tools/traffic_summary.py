@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursiv
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for k, d in agg.items():
-    if not any(t in k for t in ('conv_', 'bn_', 'wino_', 'reduce_kernel', 'first_block')):
+    if not any(t in k for t in ('conv_', 'bn_', 'wino_', 'wino2_', 'reduce_kernel', 'first_block')):
         continue
     fetch = d.get('FETCH_SIZE', [])
     write = d.get('WRITE_SIZE', [])
@@ -31,6 +31,9 @@ tot = sum(v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_byte
 wino = sum(v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch_reported']) for k, v in res.items()
            if k != '_meta' and k.startswith('wino_'))
 res['_meta']['total_bytes_per_step'] = tot / steps
+res['_meta']['onchip_winograd_bytes_per_step'] = sum(
+    v['launches'] * (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch_reported']) for k, v in res.items()
+    if k != '_meta' and k.startswith('wino2_')) / steps
 res['_meta']['wino_transform_bytes_per_step'] = wino / steps
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in list(res.items())[:40]}, indent=1)[:3000])
