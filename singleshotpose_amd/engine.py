@@ -37,7 +37,7 @@ def _tune_tag():
     return 'r6-w%s-c%s-%s-f%s' % (os.environ.get('SSP_WINO_TILES', '2,4'), os.environ.get('SSP_WINO_MIN_CHANNELS', '128'),
                                   os.environ.get('SSP_WINO4_MIN_CHANNELS', '64'),
                                   os.environ.get('SSP_WINO_FUSED', '1') + os.environ.get('SSP_WGRAD_FUSED_PREFER', '') +
-                                  os.environ.get('SSP_ONCHIP_PREFER', ''))
+                                  os.environ.get('SSP_ONCHIP_PREFER', '') + os.environ.get('SSP_ONCHIP_CREDIT_MS', ''))
 
 
 def wino_fused(code):
@@ -842,7 +842,11 @@ class Plan(object):
                             # step they share it with the data-gradient stream.  SSP_WGRAD_FUSED_PREFER (default 0.8) credits the on-chip
                             # form (no such passes) with that difference: same-box A/B of the whole step, two interleaved rounds, 26.64 / 26.45 ms
                             # with 1.0 (layers 4 / 6 stay on the F(4x4) chain) against 26.12 / 26.13 ms with 0.8 (profiles/r06_step_ab.txt)
-                            tt *= float(os.environ.get('SSP_WGRAD_FUSED_PREFER', '0.8'))
+                            # Big launches only (>= SSP_ONCHIP_CREDIT_MS, 0.25 ms alone): at batch 8 the on-chip launches are 0.15 ms
+                            # of mostly fixed cost (1024 waves x 144 atomics of flush) and the credit picked them for eight layers -
+                            # 6.49 / 6.48 ms per step against 6.33 / 6.32 without it (same box)
+                            if tt >= float(os.environ.get('SSP_ONCHIP_CREDIT_MS', '0.25')):
+                                tt *= float(os.environ.get('SSP_WGRAD_FUSED_PREFER', '0.8'))
                         if not tt < 0.985 * t_best:
                             continue
                         # verification pair: one accumulation each into zeroed buffers
@@ -1048,7 +1052,8 @@ class Plan(object):
                     # other on the 104 x 104 layers (0.50-0.61 against 0.64 ms), in the step the on-chip form is the faster one
                     # (three layers on it: 25.8 ms; one: 26.4 ms - a box whose timings fell the other way).  SSP_ONCHIP_PREFER
                     # (default 0.85) credits it accordingly; 1 = the isolated timing decides.
-                    t *= float(os.environ.get('SSP_ONCHIP_PREFER', '0.85'))
+                    if t >= float(os.environ.get('SSP_ONCHIP_CREDIT_MS', '0.25')):      # (big launches only, as for the filter gradient)
+                        t *= float(os.environ.get('SSP_ONCHIP_PREFER', '0.85'))
                 if best_t is None or t < best_t * 0.985:     # prefer earlier (simpler) candidates on near-ties
                     best, best_t = code, t
                 f_ = wino_tile(code)
