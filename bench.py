@@ -10,7 +10,8 @@ Prints ONE JSON line on rank 0.  `value` = images/s of the whole job (all ranks)
 steps between barrier + synchronize pairs, inputs resident in HBM.  `roofline` is for the dominant kernel (the
 implicit-GEMM conv kernel, forward launches): the FLOPs its MFMA pipe EXECUTED (a Winograd-plan layer counts its batched
 GEMMs, not the direct convolution) / the HIP-event time of those launches, against the fp32 MFMA peak (157.3 TFLOP/s,
-MI355X_MICROARCH.md), from HIP events inside the timed region; `launch_units` in it charges the HBM-bound Winograd
+MI355X_MICROARCH.md), from HIP events inside the timed region (on every 5th step of it: `roofline.timed_steps` - carried by
+every step the ~66 event pairs cost 0.37 ms of the step they measure); `launch_units` in it charges the HBM-bound Winograd
 transform / finishing launches to the same FLOPs, `effective` is the algorithmic (direct-convolution) rate.
 `roofline_wino_transforms` is the HBM roofline of those passes.  `roofline_dgrad` / `roofline_wgrad` (kernel-exclusive) and
 `roofline_bwd` (the two backward streams as they overlap in the step) come - like `kernel_ms_per_step` - from further,
@@ -563,13 +564,23 @@ def main():
     # <0.1 ms).  --timers all / none change that.
     # (bit 0 = the forward conv launch units, bit 9 = the Winograd transform / finishing launches inside them: the dominant
     # kernel's own time is the difference; bit 12 = the on-chip Winograd forward launches, a family of their own)
-    _lib.call('ssp_prof_enable', {'conv': (1 << 0) | (1 << 9) | (1 << 12), 'all': -1, 'none': 0}[args.timers])
+    # The event pairs are SAMPLED: every 5th step of the timed region carries them (steps 0, 5, 10, ...; ~66 pairs per step
+    # with the Winograd and on-chip families).  On every step they cost 0.37 ms of the step (same box: 25.20 / 25.22 ms with,
+    # 24.82 / 24.86 ms without them; a plain loop without the profiler hooks 24.69 ms) - an instrument should not move the
+    # number it sits next to.  `roofline.timed_steps` says how many steps the per-launch averages come from.
+    timer_mask = {'conv': (1 << 0) | (1 << 9) | (1 << 12), 'all': -1, 'none': 0}[args.timers]
+    n_timed = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if timer_mask:
+            on = (i % 5 == 0)
+            _lib.call('ssp_prof_enable', timer_mask if on else 0)
+            n_timed += 1 if on else 0
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
     _lib.call('ssp_prof_enable', 0)
+    n_timed = max(n_timed, 1)
     ms, work, cnt = collect()
     # Per-family breakdown (kernel_ms_per_step, roofline_bwd): a separate, untimed pass of the same steps with every
     # launch bracketed by events.
@@ -631,12 +642,12 @@ def main():
                            "work_per_step": bwork[k] / nb} for k in range(nk)}
         # Dominant kernel family = the implicit-GEMM conv kernel.  Its FORWARD launches run alone on the GPU, so their
         # HIP-event durations are kernel-exclusive and are taken INSIDE the timed region.
-        ig_ms, ig_flop, ig_n, ig_steps, ig_wino = ms[0], work[0], cnt[0], args.steps, ms[9]
+        ig_ms, ig_flop, ig_n, ig_steps, ig_wino = ms[0], work[0], cnt[0], n_timed, ms[9]
         if ig_ms <= 0:      # --timers none: take the forward launches of the breakdown pass
             ig_ms, ig_flop, ig_n, ig_steps, ig_wino = bms[0], bwork[0], bcnt[0], nb, bms[9]
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         # on-chip Winograd forward launches (kind 12): same source as the dominant kernel's
-        oc_fwd = (ms[12] / args.steps, cnt[12] / args.steps) if ms[0] > 0 else (bms[12] / nb, bcnt[12] / nb)
+        oc_fwd = (ms[12] / n_timed, cnt[12] / n_timed) if ms[0] > 0 else (bms[12] / nb, bcnt[12] / nb)
         # the two streams run concurrently: wall time of the conv backward ~ the longer one (on-chip launches with their stream)
         bwd_ms = max(bms[1] + bms[13], bms[2] + bms[14])
         bwd_tf = (bwork[1] + bwork[2] + bwork[13] + bwork[14]) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
@@ -726,7 +737,7 @@ def main():
         wk = {'fwd': 9, 'dgrad': 10, 'wgrad': 11}
         wino_traffic, wino_traffic_src = wino_traffic_per_step()
         # (forward passes: from the timed region itself when its timers are on, else from the untimed all-timers pass)
-        fw = (ms[9] / args.steps, work[9] / args.steps, cnt[9] / args.steps) if ms[0] > 0 else (bms[9] / nb, bwork[9] / nb, bcnt[9] / nb)
+        fw = (ms[9] / n_timed, work[9] / n_timed, cnt[9] / n_timed) if ms[0] > 0 else (bms[9] / nb, bwork[9] / nb, bcnt[9] / nb)
         hb = [hbm_family('fwd', *fw), hbm_family('dgrad', *ex[10]),
               hbm_family('wgrad', *ex[11])]
         hb_ms = sum(h["ms_per_step"] for h in hb)
@@ -757,11 +768,12 @@ def main():
             "roofline": dict(family("fwd", IGEMM % (0, 0, 0, 0, 0) + "; the forward launch units of layers 2-30 (the first block's "
                                     "two passes are first_block_kernel<0|1>: kernel_ms_per_step.first_block_fwd)",
                                     ig_ms / max(ig_steps, 1), ig_n / max(ig_steps, 1),
-                                    "HIP events around exactly these launches INSIDE the timed region (they run alone on the "
-                                    "GPU): one pair per launch unit and one per Winograd transform / finishing launch inside it; "
+                                    "HIP events around exactly these launches INSIDE the timed region, on every 5th step "
+                                    "(timed_steps; they run alone on the GPU): one pair per launch unit and one per Winograd "
+                                    "transform / finishing launch inside it; "
                                     "achieved / frac = EXECUTED MFMA FLOPs / the GEMM launches' own time",
                                     ig_wino / max(ig_steps, 1), oc_fwd[0]),
-                             traffic=traffic, traffic_source=traffic_src),
+                             traffic=traffic, traffic_source=traffic_src, timed_steps=ig_steps),
             "roofline_dgrad": family("dgrad", IGEMM % (1, 1, 1, 1, 1) + " (+ conv_igemm_kernel<64, 128, 2, 2, 4, 0, 1> for the "
                                      "20-channel head)", ex[1][0], ex[1][2],
                                      "kernel-exclusive: untimed pass with the filter gradients on the same stream "
@@ -776,7 +788,7 @@ def main():
             "roofline_onchip": {
                 "bound": "mfma",
                 "kernel": "wino2_fused_kernel<FLAGS> (csrc/conv_wino_fused.hip: forward and data gradient), wino2_wgrad_fused_kernel "
-                          "(csrc/conv_wino_wgrad_fused.hip: filter gradient incl. its zero / finishing launches)",
+                          "(csrc/conv_wino_wgrad_fused.hip: filter gradient)",
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "by_pass": {f: {"layers": fused_layers[f], "ms_per_step": round(m_, 3), "launches_per_step": n_,
                                 "achieved": round(exe_oc[f] / (m_ * 1e-3) / 1e12 if m_ > 0 else 0.0, 2),
